@@ -1,0 +1,139 @@
+"""Seeded synthetic weights and inputs.
+
+No checkpoint ships with the reference (weights live on Zenodo / HF, README.md:24-30) and
+there is no network, so tests, goldens and the benchmark all derive the *same* 190-entry
+state_dict from this recipe (numpy RandomState = frozen legacy stream).  The recipe is
+non-degenerate on purpose: the reference initialises layer-scale gamma to 1e-6
+(convnext.py:56,67-71), which would make every block an identity and hide kernel errors.
+"""
+import hashlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import frontend_tables as ft
+
+DEPTHS = (3, 3, 9, 3)
+DIMS = (96, 192, 384, 768)
+NUM_CLASSES = 527
+
+
+def state_dict_spec():
+    """Ordered (key, shape, dtype) list == reference `ConvNeXt.state_dict()` for convnext_tiny
+    with the [252,56] stem (convnext.py:641-708)."""
+    spec = [
+        ("spectrogram_extractor.stft.conv_real.weight", (ft.N_BINS, 1, ft.N_FFT), torch.float32),
+        ("spectrogram_extractor.stft.conv_imag.weight", (ft.N_BINS, 1, ft.N_FFT), torch.float32),
+        ("logmel_extractor.melW", (ft.N_BINS, ft.N_MELS), torch.float32),
+        ("bn0.weight", (ft.N_MELS,), torch.float32),
+        ("bn0.bias", (ft.N_MELS,), torch.float32),
+        ("bn0.running_mean", (ft.N_MELS,), torch.float32),
+        ("bn0.running_var", (ft.N_MELS,), torch.float32),
+        ("bn0.num_batches_tracked", (), torch.int64),
+        ("downsample_layers.0.0.weight", (DIMS[0], 1, 4, 4), torch.float32),
+        ("downsample_layers.0.0.bias", (DIMS[0],), torch.float32),
+        ("downsample_layers.0.1.weight", (DIMS[0],), torch.float32),
+        ("downsample_layers.0.1.bias", (DIMS[0],), torch.float32),
+    ]
+    for i in range(1, 4):
+        spec += [
+            ("downsample_layers.%d.0.weight" % i, (DIMS[i - 1],), torch.float32),
+            ("downsample_layers.%d.0.bias" % i, (DIMS[i - 1],), torch.float32),
+            ("downsample_layers.%d.1.weight" % i, (DIMS[i], DIMS[i - 1], 2, 2), torch.float32),
+            ("downsample_layers.%d.1.bias" % i, (DIMS[i],), torch.float32),
+        ]
+    for s in range(4):
+        C = DIMS[s]
+        for j in range(DEPTHS[s]):
+            p = "stages.%d.%d." % (s, j)
+            spec += [
+                (p + "gamma", (C,), torch.float32),
+                (p + "dwconv.weight", (C, 1, 7, 7), torch.float32),
+                (p + "dwconv.bias", (C,), torch.float32),
+                (p + "norm.weight", (C,), torch.float32),
+                (p + "norm.bias", (C,), torch.float32),
+                (p + "pwconv1.weight", (4 * C, C), torch.float32),
+                (p + "pwconv1.bias", (4 * C,), torch.float32),
+                (p + "pwconv2.weight", (C, 4 * C), torch.float32),
+                (p + "pwconv2.bias", (C,), torch.float32),
+            ]
+    spec += [
+        ("norm.weight", (DIMS[-1],), torch.float32),
+        ("norm.bias", (DIMS[-1],), torch.float32),
+        ("head_audioset.weight", (NUM_CLASSES, DIMS[-1]), torch.float32),
+        ("head_audioset.bias", (NUM_CLASSES,), torch.float32),
+    ]
+    return spec
+
+
+def _fan_in(shape):
+    n = 1
+    for d in shape[1:]:
+        n *= d
+    return n
+
+
+def synth_state_dict(seed=0):
+    """Seeded, non-degenerate weights for all 190 keys (CPU fp32 tensors)."""
+    rs = np.random.RandomState(seed)
+    real, imag = ft.stft_weights()
+    fixed = {
+        "spectrogram_extractor.stft.conv_real.weight": real,
+        "spectrogram_extractor.stft.conv_imag.weight": imag,
+        "logmel_extractor.melW": ft.mel_matrix(),
+    }
+    sd = OrderedDict()
+    for key, shape, dtype in state_dict_spec():
+        if key in fixed:
+            a = fixed[key]
+        elif key == "bn0.num_batches_tracked":
+            a = np.array(0, dtype=np.int64)
+        elif key == "bn0.running_mean":
+            a = rs.uniform(-60.0, -20.0, size=shape)
+        elif key == "bn0.running_var":
+            a = rs.uniform(50.0, 400.0, size=shape)
+        elif key.endswith("gamma"):
+            a = rs.uniform(0.1, 0.5, size=shape)
+        elif key.endswith("bias"):
+            a = 0.1 * rs.standard_normal(size=shape)
+        elif len(shape) == 1:                      # LN / BN scale
+            a = 1.0 + 0.1 * rs.standard_normal(size=shape)
+        else:                                      # conv / linear weight
+            a = rs.standard_normal(size=shape) / np.sqrt(_fan_in(shape))
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dtype).reshape(shape)
+        sd[key] = t
+    return sd
+
+
+def state_dict_digest(sd):
+    """sha256 over key names + raw bytes, to prove two sides hold the same weights."""
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def synth_waveforms(batch, length, seed=1234, kind="noise", device="cpu"):
+    """Synthetic clips (B, L) fp32.  kind: noise (sigma 0.1 ~ -20 dBFS), sweep, silence, square."""
+    if kind == "noise":
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        x = torch.randn(batch, length, generator=g, dtype=torch.float32) * 0.1
+    elif kind == "sweep":
+        t = torch.arange(length, dtype=torch.float64) / ft.SAMPLE_RATE
+        dur = length / ft.SAMPLE_RATE
+        rows = []
+        for b in range(batch):
+            f0, f1 = 60.0 * (b + 1), 12000.0 / (b + 1)
+            phase = 2 * np.pi * (f0 * t + 0.5 * (f1 - f0) / dur * t * t)
+            rows.append((0.5 * torch.sin(phase)).to(torch.float32))
+        x = torch.stack(rows)
+    elif kind == "silence":
+        x = torch.zeros(batch, length, dtype=torch.float32)
+    elif kind == "square":
+        t = torch.arange(length)
+        x = torch.where((t // 37) % 2 == 0, 1.0, -1.0).to(torch.float32)[None, :].repeat(batch, 1)
+    else:
+        raise ValueError("unknown kind %r" % kind)
+    return x.contiguous().to(device)
