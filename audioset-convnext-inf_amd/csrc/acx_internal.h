@@ -1,0 +1,136 @@
+// Internal declarations shared by the libacx translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/acx.h"
+
+namespace acx {
+
+constexpr int kDepths[4] = {3, 3, 9, 3};        // convnext.py:655
+constexpr int kDims[4] = {96, 192, 384, 768};   // convnext.py:656
+constexpr int kNFFT = 1024, kHop = 320, kBins = 513, kMels = 224;   // convnext.py:168-172
+constexpr int kClasses = ACX_NUM_CLASSES;
+constexpr int kHeadPad = 544;                   // 527 padded to a multiple of 32
+constexpr int kStemW = 56;                      // 224 mel bins / 4
+
+void set_error(const char* fmt, ...);
+
+#define ACX_FAIL(code, ...)          \
+    do {                             \
+        acx::set_error(__VA_ARGS__); \
+        return (code);               \
+    } while (0)
+
+#define ACX_HIP(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            ACX_FAIL(ACX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                              \
+    } while (0)
+
+#define ACX_TRY(expr)             \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != ACX_OK) return rc_; \
+    } while (0)
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layouts
+    float* dw = nullptr;     // [49][C]   tap-major depthwise weights
+    float* dwb = nullptr;    // [C]
+    float* w1 = nullptr;     // [4C][C]   pwconv1 with the LayerNorm weight folded in
+    float* b1 = nullptr;     // [4C]      pwconv1 bias + W1 . ln_bias
+    float* w2 = nullptr;     // [C][4C]   gamma * pwconv2
+    float* b2 = nullptr;     // [C]       gamma * pwconv2 bias
+};
+
+struct DownW {           // downsample_layers[i], i>=1 (convnext.py:230-235)
+    float* w = nullptr;      // [C'][4C]  k = (dy*2+dx)*C + c, LayerNorm weight folded in
+    float* b = nullptr;      // [C']      bias + W . ln_bias
+};
+
+struct Profile {
+    bool on = false;
+    struct Rec { int cls; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+};
+
+}  // namespace acx
+
+struct acx_ctx {
+    int device = 0;
+    bool finalized = false;
+    std::map<std::string, acx::HostTensor> host;     // raw state_dict as handed in
+    std::vector<void*> allocs;                       // every device allocation we own
+
+    // frontend
+    float* d_hann = nullptr;      // [1024]
+    float* d_twiddle = nullptr;   // [1024][2]  exp(-2 pi i n / 1024)
+    int* d_mel_start = nullptr;   // [224]
+    int* d_mel_len = nullptr;     // [224]
+    int* d_mel_off = nullptr;     // [224] offset into d_mel_w
+    float* d_mel_w = nullptr;     // banded mel weights
+    float* d_bn_scale = nullptr;  // [224]
+    float* d_bn_shift = nullptr;  // [224]
+    // stem
+    float* d_stem_w = nullptr;    // [96][16]
+    float* d_stem_b = nullptr;    // [96]
+    float* d_stem_lnw = nullptr;  // [96]
+    float* d_stem_lnb = nullptr;  // [96]
+    acx::DownW down[4];
+    std::vector<acx::BlockW> blocks[4];
+    // tail
+    float* d_norm_w = nullptr;    // [768]
+    float* d_norm_b = nullptr;
+    float* d_head_w = nullptr;    // [527][768]
+    float* d_head_b = nullptr;    // [527]
+
+    acx::Profile prof;
+};
+
+namespace acx {
+
+struct ProfScope {       // records a HIP-event pair around a launch when profiling is on
+    acx_ctx* ctx; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(acx_ctx* c, int k, hipStream_t st);
+    ~ProfScope();
+};
+
+inline int stage_h0(int T) { return (T + 8 - 4) / 4 + 1; }
+
+// ---- kernel launchers (each returns acx_status) ---------------------------------------------
+int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s);
+int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, float* out, hipStream_t s);
+int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const float* x, float* y, float* stats, int B, int H,
+                  int W, hipStream_t s);
+int launch_rowstats(acx_ctx* c, const float* x, float* stats, int64_t M, int C, hipStream_t s);
+// out[M,N] = epi( LN?(A)[M,K] . Wt[N,K]^T + bias ).
+enum GemmEpi { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
+struct GemmArgs {
+    const float* A; const float* Wt; const float* bias; float* out;
+    const float* stats;      // (rows,2) mean/rstd of the A rows (or gathered pixels); may be null
+    const float* resid;      // EPI_RESID: added to the result (may alias out)
+    int64_t M; int N; int K;
+    // 2x2 gather (downsample): A is NHWC (B,H,W,C) and row m=(b,h',w'), k=(dy*2+dx)*C+c
+    int gather; int H, W, C, Ho, Wo;
+    int epi; int cls;
+};
+int launch_gemm(acx_ctx* c, const GemmArgs& a, hipStream_t s);
+int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
+                     hipStream_t s);
+int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, int W, int C, hipStream_t s);
+
+}  // namespace acx

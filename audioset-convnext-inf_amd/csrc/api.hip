@@ -1,0 +1,529 @@
+// libacx C ABI: context lifetime, weight intake / folding / repacking, workspace planning and the
+// forward orchestration.  See include/acx.h for the contract and the reference interfaces each
+// entry point stands in for.
+#include <cmath>
+#include <cstring>
+
+#include "acx_internal.h"
+
+namespace acx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+ProfScope::ProfScope(acx_ctx* c, int k, hipStream_t st) : ctx(c), cls(k), s(st) {
+    if (!ctx || !ctx->prof.on) { ctx = nullptr; return; }
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!ctx->prof.pool.empty()) { e = ctx->prof.pool.back(); ctx->prof.pool.pop_back(); }
+        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        return e;
+    };
+    a = get(); b = get();
+    if (a) (void)hipEventRecord(a, s);
+}
+ProfScope::~ProfScope() {
+    if (!ctx) return;
+    if (b) (void)hipEventRecord(b, s);
+    ctx->prof.recs.push_back({cls, a, b});
+}
+
+struct KeySpec { std::string key; std::vector<int64_t> shape; };
+
+static std::vector<KeySpec> required_keys() {
+    std::vector<KeySpec> v;
+    v.push_back({"spectrogram_extractor.stft.conv_real.weight", {kBins, 1, kNFFT}});
+    v.push_back({"spectrogram_extractor.stft.conv_imag.weight", {kBins, 1, kNFFT}});
+    v.push_back({"logmel_extractor.melW", {kBins, kMels}});
+    for (const char* k : {"bn0.weight", "bn0.bias", "bn0.running_mean", "bn0.running_var"}) v.push_back({k, {kMels}});
+    v.push_back({"downsample_layers.0.0.weight", {kDims[0], 1, 4, 4}});
+    v.push_back({"downsample_layers.0.0.bias", {kDims[0]}});
+    v.push_back({"downsample_layers.0.1.weight", {kDims[0]}});
+    v.push_back({"downsample_layers.0.1.bias", {kDims[0]}});
+    char buf[96];
+    for (int i = 1; i < 4; ++i) {
+        snprintf(buf, sizeof buf, "downsample_layers.%d.0.weight", i); v.push_back({buf, {kDims[i - 1]}});
+        snprintf(buf, sizeof buf, "downsample_layers.%d.0.bias", i); v.push_back({buf, {kDims[i - 1]}});
+        snprintf(buf, sizeof buf, "downsample_layers.%d.1.weight", i); v.push_back({buf, {kDims[i], kDims[i - 1], 2, 2}});
+        snprintf(buf, sizeof buf, "downsample_layers.%d.1.bias", i); v.push_back({buf, {kDims[i]}});
+    }
+    for (int s = 0; s < 4; ++s) {
+        const int64_t C = kDims[s];
+        for (int j = 0; j < kDepths[s]; ++j) {
+            auto key = [&](const char* leaf) { snprintf(buf, sizeof buf, "stages.%d.%d.%s", s, j, leaf); return std::string(buf); };
+            v.push_back({key("gamma"), {C}});
+            v.push_back({key("dwconv.weight"), {C, 1, 7, 7}});
+            v.push_back({key("dwconv.bias"), {C}});
+            v.push_back({key("norm.weight"), {C}});
+            v.push_back({key("norm.bias"), {C}});
+            v.push_back({key("pwconv1.weight"), {4 * C, C}});
+            v.push_back({key("pwconv1.bias"), {4 * C}});
+            v.push_back({key("pwconv2.weight"), {C, 4 * C}});
+            v.push_back({key("pwconv2.bias"), {C}});
+        }
+    }
+    v.push_back({"norm.weight", {kDims[3]}});
+    v.push_back({"norm.bias", {kDims[3]}});
+    v.push_back({"head_audioset.weight", {kClasses, kDims[3]}});
+    v.push_back({"head_audioset.bias", {kClasses}});
+    return v;
+}
+
+static const std::vector<KeySpec>& key_table() {
+    static const std::vector<KeySpec> t = required_keys();
+    return t;
+}
+
+template <typename T>
+static int upload(acx_ctx* c, const std::vector<T>& h, T** out) {
+    void* d = nullptr;
+    ACX_HIP(hipMalloc(&d, h.size() * sizeof(T)));
+    c->allocs.push_back(d);
+    ACX_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<T*>(d);
+    return ACX_OK;
+}
+
+static void free_device(acx_ctx* c) {
+    for (void* p : c->allocs) (void)hipFree(p);
+    c->allocs.clear();
+    for (int s = 0; s < 4; ++s) c->blocks[s].clear();
+    c->finalized = false;
+}
+
+static const std::vector<float>& W(const acx_ctx* c, const std::string& k) { return c->host.at(k).data; }
+
+static int check_stft_is_hann_dft(const acx_ctx* c, std::vector<float>* hann_out) {
+    const auto& re = W(c, "spectrogram_extractor.stft.conv_real.weight");
+    const auto& im = W(c, "spectrogram_extractor.stft.conv_imag.weight");
+    std::vector<float>& hann = *hann_out;
+    hann.assign(re.begin(), re.begin() + kNFFT);      // bin 0: cos = 1, so the row IS the window
+    double worst = 0.0;
+    for (int k = 0; k < kBins; ++k) {
+        for (int n = 0; n < kNFFT; ++n) {
+            const double ang = 2.0 * M_PI * (double)(((long long)n * k) % kNFFT) / kNFFT;
+            const double er = hann[n] * std::cos(ang), ei = -(double)hann[n] * std::sin(ang);
+            worst = std::fmax(worst, std::fabs(er - re[(size_t)k * kNFFT + n]));
+            worst = std::fmax(worst, std::fabs(ei - im[(size_t)k * kNFFT + n]));
+        }
+    }
+    if (worst > 2e-6)
+        ACX_FAIL(ACX_ERR_UNSUPPORTED,
+                 "STFT buffers are not window x DFT (max deviation %.3g): the FFT frontend cannot stand in for "
+                 "spectrogram_extractor.stft.conv_real/conv_imag", worst);
+    return ACX_OK;
+}
+
+static int finalize_impl(acx_ctx* c) {
+    for (const auto& ks : key_table()) {
+        auto it = c->host.find(ks.key);
+        if (it == c->host.end()) ACX_FAIL(ACX_ERR_STATE, "missing weight '%s'", ks.key.c_str());
+    }
+    ACX_HIP(hipSetDevice(c->device));
+    free_device(c);
+
+    // ---- frontend ---------------------------------------------------------------------------
+    std::vector<float> hann;
+    ACX_TRY(check_stft_is_hann_dft(c, &hann));
+    ACX_TRY(upload(c, hann, &c->d_hann));
+    std::vector<float> tw(2 * kNFFT);
+    for (int n = 0; n < kNFFT; ++n) {
+        const double a = -2.0 * M_PI * n / kNFFT;
+        tw[2 * n] = (float)std::cos(a);
+        tw[2 * n + 1] = (float)std::sin(a);
+    }
+    ACX_TRY(upload(c, tw, &c->d_twiddle));
+    {
+        const auto& melW = W(c, "logmel_extractor.melW");     // [513][224]
+        std::vector<int> start(kMels), len(kMels), off(kMels);
+        std::vector<float> band;
+        for (int m = 0; m < kMels; ++m) {
+            int lo = -1, hi = -1;
+            for (int k = 0; k < kBins; ++k)
+                if (melW[(size_t)k * kMels + m] != 0.f) { if (lo < 0) lo = k; hi = k; }
+            start[m] = lo < 0 ? 0 : lo;
+            len[m] = lo < 0 ? 0 : hi - lo + 1;
+            off[m] = (int)band.size();
+            for (int k = 0; k < len[m]; ++k) band.push_back(melW[(size_t)(start[m] + k) * kMels + m]);
+        }
+        if (band.empty()) band.push_back(0.f);
+        ACX_TRY(upload(c, start, &c->d_mel_start));
+        ACX_TRY(upload(c, len, &c->d_mel_len));
+        ACX_TRY(upload(c, off, &c->d_mel_off));
+        ACX_TRY(upload(c, band, &c->d_mel_w));
+    }
+    {
+        const auto &w = W(c, "bn0.weight"), &b = W(c, "bn0.bias"), &mu = W(c, "bn0.running_mean"),
+                   &var = W(c, "bn0.running_var");
+        std::vector<float> sc(kMels), sh(kMels);
+        for (int m = 0; m < kMels; ++m) {
+            const double s = (double)w[m] / std::sqrt((double)var[m] + 1e-5);   // BatchNorm2d eps default
+            sc[m] = (float)s;
+            sh[m] = (float)((double)b[m] - (double)mu[m] * s);
+        }
+        ACX_TRY(upload(c, sc, &c->d_bn_scale));
+        ACX_TRY(upload(c, sh, &c->d_bn_shift));
+    }
+    // ---- stem -------------------------------------------------------------------------------
+    ACX_TRY(upload(c, W(c, "downsample_layers.0.0.weight"), &c->d_stem_w));
+    ACX_TRY(upload(c, W(c, "downsample_layers.0.0.bias"), &c->d_stem_b));
+    ACX_TRY(upload(c, W(c, "downsample_layers.0.1.weight"), &c->d_stem_lnw));
+    ACX_TRY(upload(c, W(c, "downsample_layers.0.1.bias"), &c->d_stem_lnb));
+    // ---- downsample convs: LayerNorm affine folded, K ordered (dy,dx,c) ------------------------
+    char buf[96];
+    for (int i = 1; i < 4; ++i) {
+        const int Ci = kDims[i - 1], Co = kDims[i];
+        auto key = [&](const char* leaf) { snprintf(buf, sizeof buf, "downsample_layers.%d.%s", i, leaf); return std::string(buf); };
+        const auto &lnw = W(c, key("0.weight")), &lnb = W(c, key("0.bias")), &cw = W(c, key("1.weight")),
+                   &cb = W(c, key("1.bias"));
+        std::vector<float> w((size_t)Co * 4 * Ci), b(Co);
+        for (int n = 0; n < Co; ++n) {
+            double acc = cb[n];
+            for (int ci = 0; ci < Ci; ++ci)
+                for (int q = 0; q < 4; ++q) {
+                    const float v = cw[(((size_t)n * Ci + ci) * 2 + (q >> 1)) * 2 + (q & 1)];
+                    w[(size_t)n * 4 * Ci + (size_t)q * Ci + ci] = (float)((double)v * lnw[ci]);
+                    acc += (double)v * lnb[ci];
+                }
+            b[n] = (float)acc;
+        }
+        ACX_TRY(upload(c, w, &c->down[i].w));
+        ACX_TRY(upload(c, b, &c->down[i].b));
+    }
+    // ---- blocks -----------------------------------------------------------------------------
+    for (int s = 0; s < 4; ++s) {
+        const int C = kDims[s];
+        for (int j = 0; j < kDepths[s]; ++j) {
+            auto key = [&](const char* leaf) { snprintf(buf, sizeof buf, "stages.%d.%d.%s", s, j, leaf); return std::string(buf); };
+            const auto &gamma = W(c, key("gamma")), &dw = W(c, key("dwconv.weight")), &dwb = W(c, key("dwconv.bias")),
+                       &lnw = W(c, key("norm.weight")), &lnb = W(c, key("norm.bias")), &w1 = W(c, key("pwconv1.weight")),
+                       &b1 = W(c, key("pwconv1.bias")), &w2 = W(c, key("pwconv2.weight")), &b2 = W(c, key("pwconv2.bias"));
+            BlockW bw;
+            std::vector<float> t((size_t)49 * C);
+            for (int ch = 0; ch < C; ++ch)
+                for (int tap = 0; tap < 49; ++tap) t[(size_t)tap * C + ch] = dw[(size_t)ch * 49 + tap];
+            ACX_TRY(upload(c, t, &bw.dw));
+            ACX_TRY(upload(c, dwb, &bw.dwb));
+            std::vector<float> f1((size_t)4 * C * C), fb1((size_t)4 * C);
+            for (int n = 0; n < 4 * C; ++n) {
+                double acc = b1[n];
+                for (int k = 0; k < C; ++k) {
+                    const float v = w1[(size_t)n * C + k];
+                    f1[(size_t)n * C + k] = (float)((double)v * lnw[k]);
+                    acc += (double)v * lnb[k];
+                }
+                fb1[n] = (float)acc;
+            }
+            ACX_TRY(upload(c, f1, &bw.w1));
+            ACX_TRY(upload(c, fb1, &bw.b1));
+            std::vector<float> f2((size_t)C * 4 * C), fb2(C);
+            for (int n = 0; n < C; ++n) {
+                for (int k = 0; k < 4 * C; ++k) f2[(size_t)n * 4 * C + k] = (float)((double)gamma[n] * w2[(size_t)n * 4 * C + k]);
+                fb2[n] = (float)((double)gamma[n] * b2[n]);
+            }
+            ACX_TRY(upload(c, f2, &bw.w2));
+            ACX_TRY(upload(c, fb2, &bw.b2));
+            c->blocks[s].push_back(bw);
+        }
+    }
+    // ---- tail -------------------------------------------------------------------------------
+    ACX_TRY(upload(c, W(c, "norm.weight"), &c->d_norm_w));
+    ACX_TRY(upload(c, W(c, "norm.bias"), &c->d_norm_b));
+    ACX_TRY(upload(c, W(c, "head_audioset.weight"), &c->d_head_w));
+    ACX_TRY(upload(c, W(c, "head_audioset.bias"), &c->d_head_b));
+    c->finalized = true;
+    return ACX_OK;
+}
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Plan {          // workspace carve-up for one forward
+    int T, Hs[4], Ws[4];
+    size_t off_feat, off_x[4], off_y, off_hidden, off_stats, total;
+};
+
+static int make_plan(int B, int64_t L, Plan* p) {
+    if (B <= 0) ACX_FAIL(ACX_ERR_ARG, "batch size must be positive (got %d)", B);
+    if (L < ACX_MIN_SAMPLES)
+        ACX_FAIL(ACX_ERR_SHAPE,
+                 "clip of %lld samples is too short: the last 2x2 downsample needs at least %d samples "
+                 "(kernel size can't be greater than actual input size)", (long long)L, ACX_MIN_SAMPLES);
+    p->T = (int)(L / kHop + 1);
+    p->Hs[0] = stage_h0(p->T);
+    p->Ws[0] = kStemW;
+    for (int s = 1; s < 4; ++s) { p->Hs[s] = p->Hs[s - 1] / 2; p->Ws[s] = p->Ws[s - 1] / 2; }
+    size_t off = 0;
+    p->off_feat = off; off += align_up((size_t)B * p->T * kMels * 4);
+    for (int s = 0; s < 4; ++s) { p->off_x[s] = off; off += align_up((size_t)B * p->Hs[s] * p->Ws[s] * kDims[s] * 4); }
+    const size_t pix0 = (size_t)B * p->Hs[0] * p->Ws[0];
+    p->off_y = off; off += align_up(pix0 * kDims[0] * 4);
+    p->off_hidden = off; off += align_up(pix0 * 4 * kDims[0] * 4);
+    p->off_stats = off; off += align_up(pix0 * 2 * 4);
+    p->total = off;
+    return ACX_OK;
+}
+
+static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden, float* stats, int B, int H, int Wd,
+                     hipStream_t st) {
+    const int C = kDims[s];
+    const BlockW& bw = c->blocks[s][j];
+    const int64_t M = (int64_t)B * H * Wd;
+    ACX_TRY(launch_dwconv(c, bw, C, x, y, stats, B, H, Wd, st));
+    GemmArgs g1{};
+    g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.M = M; g1.N = 4 * C; g1.K = C;
+    g1.epi = EPI_GELU; g1.cls = ACX_K_PW1;
+    ACX_TRY(launch_gemm(c, g1, st));
+    GemmArgs g2{};
+    g2.A = hidden; g2.Wt = bw.w2; g2.bias = bw.b2; g2.out = x; g2.resid = x; g2.M = M; g2.N = C; g2.K = 4 * C;
+    g2.epi = EPI_RESID; g2.cls = ACX_K_PW2;
+    ACX_TRY(launch_gemm(c, g2, st));
+    return ACX_OK;
+}
+
+static int run_downsample(acx_ctx* c, int i, const float* x, float* out, float* stats, int B, int H, int Wd,
+                          hipStream_t st) {
+    const int Ci = kDims[i - 1], Co = kDims[i];
+    ACX_TRY(launch_rowstats(c, x, stats, (int64_t)B * H * Wd, Ci, st));
+    GemmArgs g{};
+    g.A = x; g.Wt = c->down[i].w; g.bias = c->down[i].b; g.out = out; g.stats = stats;
+    g.gather = 1; g.H = H; g.W = Wd; g.C = Ci; g.Ho = H / 2; g.Wo = Wd / 2;
+    g.M = (int64_t)B * g.Ho * g.Wo; g.N = Co; g.K = 4 * Ci; g.epi = EPI_BIAS; g.cls = ACX_K_DOWNSAMPLE;
+    return launch_gemm(c, g, st);
+}
+
+static int need_ready(const acx_ctx* c) {
+    if (!c) ACX_FAIL(ACX_ERR_ARG, "null context");
+    if (!c->finalized) ACX_FAIL(ACX_ERR_STATE, "weights not finalized: call acx_set_weight for every key, then acx_finalize");
+    return ACX_OK;
+}
+
+static int check_stage(int stage, int block) {
+    if (stage < 0 || stage > 3 || block < 0 || block >= kDepths[stage])
+        ACX_FAIL(ACX_ERR_ARG, "no block %d in stage %d", block, stage);
+    return ACX_OK;
+}
+
+}  // namespace acx
+
+using namespace acx;
+
+extern "C" {
+
+const char* acx_last_error(void) { return g_err; }
+int acx_version(void) { return 100; }
+
+int acx_create(int hip_device, acx_ctx** out) {
+    if (!out) ACX_FAIL(ACX_ERR_ARG, "acx_create: out is null");
+    int n = 0;
+    ACX_HIP(hipGetDeviceCount(&n));
+    if (hip_device < 0 || hip_device >= n) ACX_FAIL(ACX_ERR_ARG, "acx_create: device %d out of range (%d visible)", hip_device, n);
+    hipDeviceProp_t prop;
+    ACX_HIP(hipGetDeviceProperties(&prop, hip_device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        ACX_FAIL(ACX_ERR_UNSUPPORTED, "acx_create: device %d is %s; this library is built for gfx950 (MI355X) only",
+                 hip_device, prop.gcnArchName);
+    acx_ctx* c = new acx_ctx();
+    c->device = hip_device;
+    *out = c;
+    return ACX_OK;
+}
+
+void acx_destroy(acx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_device(c);
+    for (auto& r : c->prof.recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
+    for (auto e : c->prof.pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int acx_set_weight(acx_ctx* c, const char* key, const float* host_data, const int64_t* shape, int ndim) {
+    if (!c || !key || !host_data || (ndim > 0 && !shape)) ACX_FAIL(ACX_ERR_ARG, "acx_set_weight: null argument");
+    for (const auto& ks : key_table()) {
+        if (ks.key != key) continue;
+        if ((int)ks.shape.size() != ndim) ACX_FAIL(ACX_ERR_SHAPE, "'%s': expected %d dims, got %d", key, (int)ks.shape.size(), ndim);
+        size_t n = 1;
+        for (int d = 0; d < ndim; ++d) {
+            if (shape[d] != ks.shape[d]) ACX_FAIL(ACX_ERR_SHAPE, "'%s': dim %d is %lld, expected %lld", key, d, (long long)shape[d], (long long)ks.shape[d]);
+            n *= (size_t)shape[d];
+        }
+        HostTensor& t = c->host[key];
+        t.shape.assign(shape, shape + ndim);
+        t.data.assign(host_data, host_data + n);
+        c->finalized = false;
+        return ACX_OK;
+    }
+    ACX_FAIL(ACX_ERR_ARG, "acx_set_weight: unexpected key '%s'", key);
+}
+
+int acx_finalize(acx_ctx* c) {
+    if (!c) ACX_FAIL(ACX_ERR_ARG, "null context");
+    int rc = finalize_impl(c);
+    if (rc != ACX_OK) { free_device(c); }
+    return rc;
+}
+
+int acx_num_frames(int64_t L, int* T) {
+    if (!T || L < 0) ACX_FAIL(ACX_ERR_ARG, "acx_num_frames: bad argument");
+    *T = (int)(L / kHop + 1);
+    return ACX_OK;
+}
+
+int acx_stage_hw(int64_t L, int stage, int* H, int* Wd) {
+    if (!H || !Wd || stage < 0 || stage > 3) ACX_FAIL(ACX_ERR_ARG, "acx_stage_hw: bad argument");
+    Plan p;
+    ACX_TRY(make_plan(1, L, &p));
+    *H = p.Hs[stage]; *Wd = p.Ws[stage];
+    return ACX_OK;
+}
+
+int acx_workspace_bytes(const acx_ctx* c, int B, int64_t L, int mode, size_t* out_bytes) {
+    (void)c;
+    if (!out_bytes || mode < 0 || mode > 2) ACX_FAIL(ACX_ERR_ARG, "acx_workspace_bytes: bad argument");
+    Plan p;
+    ACX_TRY(make_plan(B, L, &p));
+    *out_bytes = p.total;
+    return ACX_OK;
+}
+
+int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float* out0, float* out1, void* workspace,
+                size_t workspace_bytes, void* stream) {
+    ACX_TRY(need_ready(c));
+    if (!wav || !out0 || !workspace) ACX_FAIL(ACX_ERR_ARG, "acx_forward: null pointer");
+    if (mode < 0 || mode > 2) ACX_FAIL(ACX_ERR_ARG, "acx_forward: bad mode %d", mode);
+    if (mode == ACX_MODE_LOGITS && !out1) ACX_FAIL(ACX_ERR_ARG, "acx_forward: logits mode needs out1 (probs)");
+    Plan p;
+    ACX_TRY(make_plan(B, L, &p));
+    if (workspace_bytes < p.total) ACX_FAIL(ACX_ERR_WORKSPACE, "workspace of %zu bytes is smaller than the %zu needed", workspace_bytes, p.total);
+    if (((uintptr_t)workspace & 255) != 0) ACX_FAIL(ACX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* feat = (float*)(ws + p.off_feat);
+    float* x[4];
+    for (int s = 0; s < 4; ++s) x[s] = (float*)(ws + p.off_x[s]);
+    float* y = (float*)(ws + p.off_y);
+    float* hidden = (float*)(ws + p.off_hidden);
+    float* stats = (float*)(ws + p.off_stats);
+
+    ACX_TRY(launch_logmel(c, wav, B, L, p.T, feat, true, st));
+    ACX_TRY(launch_stem(c, feat, B, p.T, p.Hs[0], x[0], st));
+    for (int s = 0; s < 4; ++s) {
+        if (s > 0) ACX_TRY(run_downsample(c, s, x[s - 1], x[s], stats, B, p.Hs[s - 1], p.Ws[s - 1], st));
+        for (int j = 0; j < kDepths[s]; ++j) ACX_TRY(run_block(c, s, j, x[s], y, hidden, stats, B, p.Hs[s], p.Ws[s], st));
+    }
+    if (mode == ACX_MODE_FRAME) return launch_nhwc_to_nchw(c, x[3], out0, B, p.Hs[3], p.Ws[3], kDims[3], st);
+    if (mode == ACX_MODE_SCENE) return launch_pool_head(c, x[3], B, p.Hs[3], out0, nullptr, nullptr, st);
+    return launch_pool_head(c, x[3], B, p.Hs[3], nullptr, out0, out1, st);
+}
+
+int acx_logmel_bn0(acx_ctx* c, const float* wav, int B, int64_t L, float* out, int apply_bn0, void* stream) {
+    ACX_TRY(need_ready(c));
+    if (!wav || !out || B <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_logmel_bn0: bad argument");
+    if (L < kNFFT / 2 + 1) ACX_FAIL(ACX_ERR_SHAPE, "reflect padding needs at least %d samples (got %lld)", kNFFT / 2 + 1, (long long)L);
+    return launch_logmel(c, wav, B, L, (int)(L / kHop + 1), out, apply_bn0 != 0, (hipStream_t)stream);
+}
+
+int acx_stem_ln(acx_ctx* c, const float* in, int B, int T, float* out, void* stream) {
+    ACX_TRY(need_ready(c));
+    if (!in || !out || B <= 0 || T <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_stem_ln: bad argument");
+    return launch_stem(c, in, B, T, stage_h0(T), out, (hipStream_t)stream);
+}
+
+int acx_dwconv7(acx_ctx* c, int stage, int block, const float* x, float* y, float* stats, int B, int H, int Wd, void* stream) {
+    ACX_TRY(need_ready(c));
+    ACX_TRY(check_stage(stage, block));
+    if (!x || !y || B <= 0 || H <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_dwconv7: bad argument");
+    if (Wd != (kStemW >> stage)) ACX_FAIL(ACX_ERR_SHAPE, "stage %d has width %d, got %d", stage, kStemW >> stage, Wd);
+    return launch_dwconv(c, c->blocks[stage][block], kDims[stage], x, y, stats, B, H, Wd, (hipStream_t)stream);
+}
+
+int acx_block_mlp(acx_ctx* c, int stage, int block, const float* y, const float* stats, float* x, float* hidden, int B,
+                  int H, int Wd, void* stream) {
+    ACX_TRY(need_ready(c));
+    ACX_TRY(check_stage(stage, block));
+    if (!y || !stats || !x || !hidden || B <= 0 || H <= 0 || Wd <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_block_mlp: bad argument");
+    const int C = kDims[stage];
+    const BlockW& bw = c->blocks[stage][block];
+    const int64_t M = (int64_t)B * H * Wd;
+    GemmArgs g1{};
+    g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.M = M; g1.N = 4 * C; g1.K = C;
+    g1.epi = EPI_GELU; g1.cls = ACX_K_PW1;
+    ACX_TRY(launch_gemm(c, g1, (hipStream_t)stream));
+    GemmArgs g2{};
+    g2.A = hidden; g2.Wt = bw.w2; g2.bias = bw.b2; g2.out = x; g2.resid = x; g2.M = M; g2.N = C; g2.K = 4 * C;
+    g2.epi = EPI_RESID; g2.cls = ACX_K_PW2;
+    return launch_gemm(c, g2, (hipStream_t)stream);
+}
+
+int acx_block_scratch_bytes(int stage, int B, int H, int Wd, size_t* out_bytes) {
+    if (!out_bytes || stage < 0 || stage > 3 || B <= 0 || H <= 0 || Wd <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_block_scratch_bytes: bad argument");
+    const size_t pix = (size_t)B * H * Wd;
+    *out_bytes = align_up(pix * kDims[stage] * 4) + align_up(pix * 4 * kDims[stage] * 4) + align_up(pix * 8);
+    return ACX_OK;
+}
+
+int acx_block(acx_ctx* c, int stage, int block, float* x, int B, int H, int Wd, void* scratch, size_t scratch_bytes, void* stream) {
+    ACX_TRY(need_ready(c));
+    ACX_TRY(check_stage(stage, block));
+    if (!x || !scratch) ACX_FAIL(ACX_ERR_ARG, "acx_block: null pointer");
+    if (Wd != (kStemW >> stage)) ACX_FAIL(ACX_ERR_SHAPE, "stage %d has width %d, got %d", stage, kStemW >> stage, Wd);
+    size_t need = 0;
+    ACX_TRY(acx_block_scratch_bytes(stage, B, H, Wd, &need));
+    if (scratch_bytes < need || ((uintptr_t)scratch & 255)) ACX_FAIL(ACX_ERR_WORKSPACE, "acx_block: scratch too small (%zu < %zu) or misaligned", scratch_bytes, need);
+    const size_t pix = (size_t)B * H * Wd;
+    char* ws = (char*)scratch;
+    float* y = (float*)ws;
+    float* hidden = (float*)(ws + align_up(pix * kDims[stage] * 4));
+    float* stats = (float*)(ws + align_up(pix * kDims[stage] * 4) + align_up(pix * 4 * kDims[stage] * 4));
+    return run_block(c, stage, block, x, y, hidden, stats, B, H, Wd, (hipStream_t)stream);
+}
+
+int acx_downsample(acx_ctx* c, int i, const float* x, float* out, float* stats, int B, int H, int Wd, void* stream) {
+    ACX_TRY(need_ready(c));
+    if (i < 1 || i > 3) ACX_FAIL(ACX_ERR_ARG, "acx_downsample: layer index %d (expected 1..3)", i);
+    if (!x || !out || !stats || B <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_downsample: bad argument");
+    if (H < 2 || Wd < 2) ACX_FAIL(ACX_ERR_SHAPE, "acx_downsample: kernel size can't be greater than actual input size (%dx%d)", H, Wd);
+    return run_downsample(c, i, x, out, stats, B, H, Wd, (hipStream_t)stream);
+}
+
+int acx_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs, void* stream) {
+    ACX_TRY(need_ready(c));
+    if (!x || B <= 0 || H3 <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_pool_head: bad argument");
+    return launch_pool_head(c, x, B, H3, scene, logits, probs, (hipStream_t)stream);
+}
+
+int acx_nhwc_to_nchw(const float* x, float* out, int B, int H, int Wd, int C, void* stream) {
+    if (!x || !out || B <= 0 || H <= 0 || Wd <= 0 || C <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_nhwc_to_nchw: bad argument");
+    return launch_nhwc_to_nchw(nullptr, x, out, B, H, Wd, C, (hipStream_t)stream);
+}
+
+int acx_profile_enable(acx_ctx* c, int on) {
+    if (!c) ACX_FAIL(ACX_ERR_ARG, "null context");
+    c->prof.on = on != 0;
+    return ACX_OK;
+}
+
+int acx_profile_read(acx_ctx* c, double* ms, int64_t* launches) {
+    if (!c || !ms || !launches) ACX_FAIL(ACX_ERR_ARG, "acx_profile_read: null argument");
+    for (int k = 0; k < ACX_K_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; }
+    for (auto& r : c->prof.recs) {
+        if (r.a && r.b) {
+            ACX_HIP(hipEventSynchronize(r.b));
+            float t = 0.f;
+            ACX_HIP(hipEventElapsedTime(&t, r.a, r.b));
+            if (r.cls >= 0 && r.cls < ACX_K_COUNT) { ms[r.cls] += t; launches[r.cls] += 1; }
+        }
+        if (r.a) c->prof.pool.push_back(r.a);
+        if (r.b) c->prof.pool.push_back(r.b);
+    }
+    c->prof.recs.clear();
+    return ACX_OK;
+}
+
+}  // extern "C"

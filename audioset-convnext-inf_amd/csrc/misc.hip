@@ -1,0 +1,127 @@
+// K6 -- tail of forward_features + head (convnext.py:279-285, :321-325), and the NHWC->NCHW
+// transpose that gives forward_frame_embeddings its layout (convnext.py:276-277).
+#include "acx_internal.h"
+
+namespace acx {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum256(float v, float* red /*[4]*/) {
+    v = wave_sum(v);
+    __syncthreads();                       // protect red[] from the previous use
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One workgroup per clip.  x NHWC (B,H3,7,768):
+//   mean over the 7 frequency columns (torch.mean(x, dim=3)), then max over time + mean over time,
+//   nn.LayerNorm(768, eps=1e-6) -> scene embedding; Linear 768->527 -> logits; sigmoid -> probs.
+__global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ x, int H3,
+                                                        const float* __restrict__ nw, const float* __restrict__ nb,
+                                                        const float* __restrict__ hw, const float* __restrict__ hb,
+                                                        float* __restrict__ scene, float* __restrict__ logits,
+                                                        float* __restrict__ probs) {
+    __shared__ float emb[768];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const long long b = blockIdx.x;
+    const float* xb = x + b * (long long)H3 * 7 * 768;
+    float pooled[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c = tid + 256 * k;
+        float mx = -INFINITY, sm = 0.f;
+        for (int h = 0; h < H3; ++h) {
+            const float* r = xb + (long long)h * 7 * 768 + c;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 7; ++w) s += r[w * 768];
+            s *= (1.0f / 7.0f);
+            mx = fmaxf(mx, s);
+            sm += s;
+        }
+        pooled[k] = mx + sm / (float)H3;
+    }
+    const float mean = block_sum256(pooled[0] + pooled[1] + pooled[2], red) * (1.0f / 768.0f);
+    const float d0 = pooled[0] - mean, d1 = pooled[1] - mean, d2 = pooled[2] - mean;
+    const float var = block_sum256(d0 * d0 + d1 * d1 + d2 * d2, red) * (1.0f / 768.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    const float d[3] = {d0, d1, d2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c = tid + 256 * k;
+        const float e = fmaf(d[k] * rstd, nw[c], nb[c]);
+        emb[c] = e;
+        if (scene) scene[b * 768 + c] = e;
+    }
+    __syncthreads();
+    if (!logits && !probs) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    float4 e[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) e[k] = *reinterpret_cast<const float4*>(&emb[4 * (lane + 64 * k)]);
+    for (int n = wave; n < kClasses; n += 4) {
+        const float4* wr = reinterpret_cast<const float4*>(hw + (long long)n * 768);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 w4 = wr[lane + 64 * k];
+            s = fmaf(e[k].x, w4.x, s); s = fmaf(e[k].y, w4.y, s);
+            s = fmaf(e[k].z, w4.z, s); s = fmaf(e[k].w, w4.w, s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float z = s + hb[n];
+            if (logits) logits[b * kClasses + n] = z;
+            if (probs) probs[b * kClasses + n] = 1.0f / (1.0f + expf(-z));
+        }
+    }
+}
+
+int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
+                     hipStream_t s) {
+    ProfScope ps(c, ACX_K_POOLHEAD, s);
+    pool_head_kernel<<<dim3(B), dim3(256), 0, s>>>(x, H3, c->d_norm_w, c->d_norm_b, c->d_head_w, c->d_head_b,
+                                                   scene, logits, probs);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
+// out[b][c][p] = x[b][p][c], p = h*W + w.  32x32 tiles through LDS (+1 pad), coalesced both ways.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           int P, int C) {
+    __shared__ float t[32][33];
+    const long long b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const float* xb = x + b * (long long)P * C;
+    float* ob = out + b * (long long)P * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + ty + 8 * i;
+        if (p < P) t[ty + 8 * i][tx] = xb[(long long)p * C + c0 + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i;
+        const int p = p0 + tx;
+        if (p < P) ob[(long long)c * P + p] = t[tx][ty + 8 * i];
+    }
+}
+
+int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, int W, int C, hipStream_t s) {
+    if (C % 32 != 0) ACX_FAIL(ACX_ERR_SHAPE, "nhwc_to_nchw: C=%d is not a multiple of 32", C);
+    const int P = H * W;
+    ProfScope ps(c, ACX_K_TRANSPOSE, s);
+    nhwc_to_nchw_kernel<<<dim3((P + 31) / 32, C / 32, B), dim3(256), 0, s>>>(x, out, P, C);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
+}  // namespace acx

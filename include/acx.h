@@ -1,0 +1,145 @@
+/* acx.h -- C ABI of libacx.so: the MI355X-native (gfx950) audio-tagging inference path.
+ *
+ * The reference (topel/audioset-convnext-inf) has no FFI layer: its boundary for this path is
+ * the Python nn.Module surface of `ConvNeXt` (src/audioset_convnext_inf/pytorch/convnext.py).
+ * Each entry point below names the reference interface it stands in for (file:line relative to
+ * the reference root).  The host-side mirror of that surface lives in
+ * audioset-convnext-inf_amd/pytorch/convnext.py and binds these symbols with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in any signature
+ *     (`stream` is a hipStream_t passed as void*; NULL = the null stream).
+ *   - every function returns ACX_OK (0) or a negative acx_status; acx_last_error() gives the
+ *     thread-local message of the last failure.
+ *   - device pointers are fp32, 16-byte aligned, caller-owned (torch tensors); the context owns
+ *     only the repacked weights.  Nothing in the launch path allocates or synchronises, so the
+ *     forward can be captured into a hipGraph and `.cpu()` on the outputs synchronises exactly
+ *     as it does in the reference.
+ *   - activations inside the library are NHWC (channels-last); NCHW appears only in the
+ *     frame-embedding output, as in the reference.
+ */
+#ifndef ACX_H
+#define ACX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(ACX_BUILD)
+#define ACX_API __attribute__((visibility("default")))
+#else
+#define ACX_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct acx_ctx acx_ctx;
+
+enum acx_status {
+    ACX_OK = 0,
+    ACX_ERR_ARG = -1,         /* null pointer, bad enum, bad key */
+    ACX_ERR_STATE = -2,       /* weights missing / not finalized */
+    ACX_ERR_HIP = -3,         /* a HIP runtime call failed */
+    ACX_ERR_SHAPE = -4,       /* tensor shape does not match the model, or clip too short */
+    ACX_ERR_WORKSPACE = -5,   /* workspace too small or misaligned */
+    ACX_ERR_UNSUPPORTED = -6  /* e.g. STFT buffers that are not hann x DFT */
+};
+
+enum acx_mode {
+    ACX_MODE_LOGITS = 0,      /* ConvNeXt.forward                  convnext.py:287-331 */
+    ACX_MODE_SCENE = 1,       /* ConvNeXt.forward_scene_embeddings convnext.py:333-366 */
+    ACX_MODE_FRAME = 2        /* ConvNeXt.forward_frame_embeddings convnext.py:369-402 */
+};
+
+/* kernel classes for acx_profile_read() */
+enum acx_kernel_class {
+    ACX_K_FRONTEND = 0, ACX_K_STEM, ACX_K_DWCONV, ACX_K_PW1, ACX_K_PW2, ACX_K_ROWSTATS,
+    ACX_K_DOWNSAMPLE, ACX_K_POOLHEAD, ACX_K_TRANSPOSE, ACX_K_COUNT
+};
+
+#define ACX_MIN_SAMPLES 7360  /* shortest clip the reference accepts (last 2x2 downsample needs H>=2) */
+#define ACX_NUM_CLASSES 527   /* convnext.py:654 */
+#define ACX_EMBED_DIM 768     /* convnext.py:656 */
+
+ACX_API const char* acx_last_error(void);
+ACX_API int acx_version(void);
+
+/* Lifetime.  One context per process per GPU (reference: one nn.Module placed by
+ * `model.to(device)`, demo_convnext.py:44-45, evaluate_convnext_on_audioset.py:45-47). */
+ACX_API int acx_create(int hip_device, acx_ctx** out);
+ACX_API void acx_destroy(acx_ctx* ctx);
+
+/* Weights enter under the reference's own state_dict keys (the 190-key contract of
+ * `load_state_dict` / `safetensors.torch.load_model`, convnext.py:507,
+ * evaluate_convnext_on_audioset.py:36-38).  `host_data` is fp32, C-contiguous, HOST memory,
+ * borrowed for the duration of the call.  `bn0.num_batches_tracked` (int64) is not needed. */
+ACX_API int acx_set_weight(acx_ctx* ctx, const char* state_dict_key, const float* host_data,
+                   const int64_t* shape, int ndim);
+
+/* Folds and repacks for the kernels, uploads to the device:
+ *   bn0 -> per-mel scale/shift (convnext.py:304-306); melW -> banded form; verifies that the
+ *   STFT buffers are hann x DFT (else ACX_ERR_UNSUPPORTED) so that the FFT kernel may stand in
+ *   for the two Conv1d (convnext.py:179-187,298);
+ *   dwconv (C,1,7,7) -> [49][C]; LayerNorm affine of each block folded into pwconv1;
+ *   gamma folded into pwconv2 (convnext.py:78-83); downsample conv (C',C,2,2) -> [C'][4C];
+ *   head padded to 544 rows.
+ * May be called again after weights change. */
+ACX_API int acx_finalize(acx_ctx* ctx);
+
+/* Geometry helpers: frames T = L/320+1 (torchlibrosa STFT, hop 320, center) and the spatial size
+ * after the stem / each downsample (convnext.py:688-691, 230-235). */
+ACX_API int acx_num_frames(int64_t L, int* T);
+ACX_API int acx_stage_hw(int64_t L, int stage, int* H, int* W);
+
+ACX_API int acx_workspace_bytes(const acx_ctx* ctx, int B, int64_t L, int mode, size_t* out_bytes);
+
+/* The hot path.  wav: device (B, L) fp32.
+ *   ACX_MODE_LOGITS: out0 = logits (B,527), out1 = probs (B,527)   [dict keys
+ *                    "clipwise_logits" / "clipwise_output", convnext.py:329]
+ *   ACX_MODE_SCENE : out0 = (B,768), out1 ignored
+ *   ACX_MODE_FRAME : out0 = NCHW (B,768,H3,7), out1 ignored */
+ACX_API int acx_forward(acx_ctx* ctx, const float* wav, int B, int64_t L, int mode, float* out0,
+                float* out1, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-kernel entry points (golden-vector tests, rocprofv3 isolation, roofline bench) ---- */
+
+/* K1: Spectrogram + LogmelFilterBank + bn0 (convnext.py:298-306). out (B,T,224). */
+ACX_API int acx_logmel_bn0(acx_ctx* ctx, const float* wav, int B, int64_t L, float* out, int apply_bn0,
+                   void* stream);
+/* K2: stem Conv2d(1,96,4x4,s4,pad(4,0)) + LayerNorm (convnext.py:688-691,227).
+ * in (B,T,224) -> out NHWC (B,H0,56,96). */
+ACX_API int acx_stem_ln(acx_ctx* ctx, const float* in, int B, int T, float* out, void* stream);
+/* K3: Block.dwconv 7x7 depthwise + bias (convnext.py:58-60,76), NHWC in/out, plus the per-pixel
+ * LayerNorm statistics (mean, rstd) of the output (convnext.py:78) into stats (B*H*W, 2). */
+ACX_API int acx_dwconv7(acx_ctx* ctx, int stage, int block, const float* x, float* y, float* stats, int B,
+                int H, int W, void* stream);
+/* K4: LayerNorm + pwconv1 + GELU + pwconv2 + gamma + residual (convnext.py:78-86).
+ * y, stats from acx_dwconv7; x updated in place; hidden = scratch (B*H*W, 4C) fp32. */
+ACX_API int acx_block_mlp(acx_ctx* ctx, int stage, int block, const float* y, const float* stats, float* x,
+                  float* hidden, int B, int H, int W, void* stream);
+/* whole Block.forward (convnext.py:74-87) on NHWC x, in place. scratch >= acx_block_scratch_bytes */
+ACX_API int acx_block(acx_ctx* ctx, int stage, int block, float* x, int B, int H, int W, void* scratch,
+              size_t scratch_bytes, void* stream);
+ACX_API int acx_block_scratch_bytes(int stage, int B, int H, int W, size_t* out_bytes);
+/* K5: downsample_layers[i], i=1..3: LayerNorm + Conv2d 2x2 s2 (convnext.py:230-235).
+ * x NHWC (B,H,W,C_{i-1}) -> out NHWC (B,H/2,W/2,C_i); stats scratch (B*H*W,2). */
+ACX_API int acx_downsample(acx_ctx* ctx, int i, const float* x, float* out, float* stats, int B, int H,
+                   int W, void* stream);
+/* K6: pooling + final LayerNorm + head + sigmoid (convnext.py:279-285,321-325).
+ * x NHWC (B,H3,7,768). Any of scene/logits/probs may be NULL. */
+ACX_API int acx_pool_head(acx_ctx* ctx, const float* x, int B, int H3, float* scene, float* logits,
+                  float* probs, void* stream);
+/* NHWC -> NCHW (the layout forward_frame_embeddings returns, convnext.py:276-277). */
+ACX_API int acx_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, void* stream);
+
+/* ---- measurement: per-kernel-class device time, HIP events on the launch stream ------------ */
+ACX_API int acx_profile_enable(acx_ctx* ctx, int on);
+/* Synchronises the recorded events; fills ms[ACX_K_COUNT], launches[ACX_K_COUNT]; resets. */
+ACX_API int acx_profile_read(acx_ctx* ctx, double* ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACX_H */
