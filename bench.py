@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Headline benchmark: clips/sec of the audio-tagging hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--mode logits|scene|frame]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+One "step" = one pass of the hot path (waveform -> logits+probs) over one batch of synthetic 10 s /
+32 kHz clips that is already resident in HBM.  N = 1 runs BASELINE config 2 (ConvNeXt-Tiny, bs=64,
+fp32); N > 1 keeps 64 clips per GPU (weak scaling: clips are independent, every rank holds a full
+weight replica) and includes the one collective of the path -- the RCCL all-gather of the logits --
+in the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- the dominant kernel class (the fp32-MFMA pointwise GEMMs): algorithmic FLOPs per
+                  launch / average launch duration (HIP events on the launch stream, taken in a separate
+                  profiled pass of the same workload so that event overhead stays out of `value`).
+  kernels      -- the same for every kernel class, with the HBM roofline for the byte-bound ones.
+  cpu_baseline -- the CPU oracle (oracle/ref_cpu.py, torch-CPU fp32, the reference's op sequence) timed
+                  on this box's host cores on a bounded sample of the same workload (N = 1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from audioset_convnext_inf_amd import _ffi, synth                      # noqa: E402
+from audioset_convnext_inf_amd.pytorch.convnext import convnext_tiny   # noqa: E402
+
+CLIP_SAMPLES = 320000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured-achievable)
+MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA, dense (no xf32 on gfx950)
+DIMS, DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
+
+
+def algorithmic_work(B, L):
+    """Per kernel class: (total FLOPs, total algorithmic HBM bytes) of ONE forward."""
+    T = L // 320 + 1
+    hs = [(T + 4) // 4 + 1]
+    ws = [56]
+    for _ in range(3):
+        hs.append(hs[-1] // 2)
+        ws.append(ws[-1] // 2)
+    pix = [B * h * w for h, w in zip(hs, ws)]
+    work = {k: [0.0, 0.0] for k in _ffi.KERNEL_CLASSES}
+    work["frontend"] = [0.0, B * L * 4 + B * T * 224 * 4]
+    work["stem"] = [2.0 * pix[0] * 16 * 96, B * T * 224 * 4 + pix[0] * 96 * 4]
+    for s in range(4):
+        C = DIMS[s]
+        n = DEPTHS[s]
+        work["dwconv"][0] += n * 2.0 * 49 * pix[s] * C
+        work["dwconv"][1] += n * 2.0 * pix[s] * C * 4                      # read x, write y
+        work["rowstats"][1] += n * 1.0 * pix[s] * C * 4
+        work["pw1"][0] += n * 2.0 * pix[s] * C * 4 * C
+        work["pw1"][1] += n * (pix[s] * C * 4 + pix[s] * 4 * C * 4)        # unfused: y in, hidden out
+        work["pw2"][0] += n * 2.0 * pix[s] * C * 4 * C
+        work["pw2"][1] += n * (pix[s] * 4 * C * 4 + 2.0 * pix[s] * C * 4)  # hidden in, x in/out
+        if s > 0:
+            work["downsample"][0] += 2.0 * pix[s] * 4 * DIMS[s - 1] * C
+            work["downsample"][1] += pix[s - 1] * DIMS[s - 1] * 4 + pix[s] * C * 4
+            work["rowstats"][1] += pix[s - 1] * DIMS[s - 1] * 4
+    work["poolhead"] = [2.0 * B * 768 * 527, pix[3] * 768 * 4]
+    return work
+
+
+def cpu_baseline(batch=8, reps=3):
+    """Time the oracle on the host cores.  torch-CPU scales badly past a few dozen threads on this graph
+    (and the box may expose more logical CPUs than it grants), so first probe a few thread counts on one
+    clip, then time `batch` 10 s clips per call with the best one: best of `reps` after the warm-up."""
+    from oracle import ref_cpu
+    sd = synth.synth_state_dict(0)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    wav = synth.synth_waveforms(batch, CLIP_SAMPLES, seed=1234)
+    probe = {}
+    for n in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(n)
+        ref_cpu.forward(sd, wav[:1])
+        t0 = time.perf_counter()
+        ref_cpu.forward(sd, wav[:2])
+        probe[n] = 2 / (time.perf_counter() - t0)
+    threads = max(probe, key=probe.get)
+    torch.set_num_threads(threads)
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ref_cpu.forward(sd, wav)
+        best = min(best, time.perf_counter() - t0)
+    value = max(batch / best, probe[threads])
+    return {"value": value, "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "%d clips x 10 s @ 32 kHz through oracle/ref_cpu.forward (torch-CPU fp32, the reference's op "
+                      "sequence), best of %d; thread-count probe (clips/s on 2 clips): %s; %d logical CPUs available"
+                      % (batch, reps, {k: round(v, 2) for k, v in probe.items()}, avail)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--mode", default="logits", choices=["logits", "scene", "frame"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from audioset_convnext_inf_amd import parallel
+    model = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
+                          use_speed_perturb=False)
+    model.load_state_dict(synth.synth_state_dict(0))
+    model = model.to(dev).eval()
+    B = args.batch
+    wav = synth.synth_waveforms(B, CLIP_SAMPLES, seed=1234 + rank).to(dev)
+    fn = {"logits": lambda: model(wav)["clipwise_logits"], "scene": lambda: model.forward_scene_embeddings(wav),
+          "frame": lambda: model.forward_frame_embeddings(wav)}[args.mode]
+
+    def step():
+        out = fn()
+        if world > 1 and args.mode != "frame":        # frame embeddings stay sharded
+            out = parallel.all_gather_rows(out)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    line = {
+        "metric": "clips/sec (10 s @ 32 kHz, ConvNeXt-Tiny, bs=64)", "value": world * B * args.steps / elapsed,
+        "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ConvNeXt-Tiny bs=%d per GPU, synthetic 10 s @ 32 kHz waveforms resident in HBM, "
+                               "waveform -> %s, fp32 (BASELINE configs[1])" % (B, args.mode),
+                   "global_batch": world * B, "clip_samples": CLIP_SAMPLES, "weights": "seeded synthetic (synth.py)",
+                   "parallelism": "clips sharded %d-way, full weight replica per GPU, RCCL all-gather of logits"
+                                  % world if world > 1 else "single GPU"},
+    }
+
+    if rank == 0 and not args.no_profile:
+        ctx = model.native_context(dev)
+        ctx.profile(True)
+        n_prof = max(1, min(args.steps, 5))
+        for _ in range(n_prof):
+            fn()
+        torch.cuda.synchronize(dev)
+        prof = ctx.profile_read()
+        ctx.profile(False)
+        work = algorithmic_work(B, CLIP_SAMPLES)
+        kernels = {}
+        for k, (ms, n) in prof.items():
+            if n == 0:
+                continue
+            flops, nbytes = work[k][0] * n_prof, work[k][1] * n_prof
+            kernels[k] = {"launches_per_step": n // n_prof, "ms_per_step": ms / n_prof,
+                          "tflops": flops / (ms * 1e-3) / 1e12 if flops else None,
+                          "algorithmic_GBs": nbytes / (ms * 1e-3) / 1e9}
+        line["kernels"] = kernels
+        dom = max(("pw1", "pw2"), key=lambda k: kernels[k]["ms_per_step"])
+        per_launch_flops = work[dom][0] / (sum(DEPTHS))
+        avg_launch_s = kernels[dom]["ms_per_step"] * 1e-3 / kernels[dom]["launches_per_step"]
+        ach = per_launch_flops / avg_launch_s / 1e12
+        line["roofline"] = {"kernel": "gemm_f32_kernel (%s)" % ("pwconv1+GELU" if dom == "pw1" else "pwconv2+residual"),
+                            "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                            "avg_launch_ms": avg_launch_s * 1e3, "flops_per_launch": per_launch_flops}
+        dw = kernels["dwconv"]
+        line["roofline_dwconv"] = {"kernel": "dwconv7_kernel", "bound": "hbm", "achieved": dw["algorithmic_GBs"],
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dw["algorithmic_GBs"] / HBM_PEAK_GBS,
+                                   "traffic": None}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
