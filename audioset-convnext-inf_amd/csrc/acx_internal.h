@@ -52,6 +52,7 @@ struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layou
     float* dwb = nullptr;    // [C]
     float* w1 = nullptr;     // [4C][C]   pwconv1 with the LayerNorm weight folded in
     float* b1 = nullptr;     // [4C]      pwconv1 bias + W1 . ln_bias
+    float* w1sum = nullptr;  // [4C]      sum_k w1[n][k]  (LayerNorm applied in the GEMM epilogue)
     float* w2 = nullptr;     // [C][4C]   gamma * pwconv2
     float* b2 = nullptr;     // [C]       gamma * pwconv2 bias
 };
@@ -117,11 +118,14 @@ int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, float* out, h
 int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const float* x, float* y, float* stats, int B, int H,
                   int W, hipStream_t s);
 int launch_rowstats(acx_ctx* c, const float* x, float* stats, int64_t M, int C, hipStream_t s);
+// out[row] = (x[row] - mean) * rstd (no affine), rows of C channels; out may alias x
+int launch_layernorm_rows(acx_ctx* c, const float* x, float* out, int64_t M, int C, hipStream_t s);
 // out[M,N] = epi( LN?(A)[M,K] . Wt[N,K]^T + bias ).
 enum GemmEpi { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
 struct GemmArgs {
     const float* A; const float* Wt; const float* bias; float* out;
-    const float* stats;      // (rows,2) mean/rstd of the A rows (or gathered pixels); may be null
+    const float* stats;      // EPI_GELU: (M,2) mean/rstd of the A rows -- LayerNorm applied in the epilogue
+    const float* colsum;     // EPI_GELU: (N) sum_k Wt[n][k]
     const float* resid;      // EPI_RESID: added to the result (may alias out)
     int64_t M; int N; int K;
     // 2x2 gather (downsample): A is NHWC (B,H,W,C) and row m=(b,h',w'), k=(dy*2+dx)*C+c

@@ -210,18 +210,22 @@ static int finalize_impl(acx_ctx* c) {
                 for (int tap = 0; tap < 49; ++tap) t[(size_t)tap * C + ch] = dw[(size_t)ch * 49 + tap];
             ACX_TRY(upload(c, t, &bw.dw));
             ACX_TRY(upload(c, dwb, &bw.dwb));
-            std::vector<float> f1((size_t)4 * C * C), fb1((size_t)4 * C);
+            std::vector<float> f1((size_t)4 * C * C), fb1((size_t)4 * C), fs1((size_t)4 * C);
             for (int n = 0; n < 4 * C; ++n) {
-                double acc = b1[n];
+                double acc = b1[n], csum = 0.0;
                 for (int k = 0; k < C; ++k) {
                     const float v = w1[(size_t)n * C + k];
-                    f1[(size_t)n * C + k] = (float)((double)v * lnw[k]);
+                    const float f = (float)((double)v * lnw[k]);
+                    f1[(size_t)n * C + k] = f;
+                    csum += (double)f;                      // of the fp32 values the GEMM really multiplies
                     acc += (double)v * lnb[k];
                 }
                 fb1[n] = (float)acc;
+                fs1[n] = (float)csum;
             }
             ACX_TRY(upload(c, f1, &bw.w1));
             ACX_TRY(upload(c, fb1, &bw.b1));
+            ACX_TRY(upload(c, fs1, &bw.w1sum));
             std::vector<float> f2((size_t)C * 4 * C), fb2(C);
             for (int n = 0; n < C; ++n) {
                 for (int k = 0; k < 4 * C; ++k) f2[(size_t)n * 4 * C + k] = (float)((double)gamma[n] * w2[(size_t)n * 4 * C + k]);
@@ -276,7 +280,7 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     const int64_t M = (int64_t)B * H * Wd;
     ACX_TRY(launch_dwconv(c, bw, C, x, y, stats, B, H, Wd, st));
     GemmArgs g1{};
-    g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.M = M; g1.N = 4 * C; g1.K = C;
+    g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.colsum = bw.w1sum; g1.M = M; g1.N = 4 * C; g1.K = C;
     g1.epi = EPI_GELU; g1.cls = ACX_K_PW1;
     ACX_TRY(launch_gemm(c, g1, st));
     GemmArgs g2{};
@@ -286,12 +290,12 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     return ACX_OK;
 }
 
-static int run_downsample(acx_ctx* c, int i, const float* x, float* out, float* stats, int B, int H, int Wd,
+static int run_downsample(acx_ctx* c, int i, const float* x, float* out, float* xnorm, int B, int H, int Wd,
                           hipStream_t st) {
     const int Ci = kDims[i - 1], Co = kDims[i];
-    ACX_TRY(launch_rowstats(c, x, stats, (int64_t)B * H * Wd, Ci, st));
+    ACX_TRY(launch_layernorm_rows(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
     GemmArgs g{};
-    g.A = x; g.Wt = c->down[i].w; g.bias = c->down[i].b; g.out = out; g.stats = stats;
+    g.A = xnorm; g.Wt = c->down[i].w; g.bias = c->down[i].b; g.out = out;
     g.gather = 1; g.H = H; g.W = Wd; g.C = Ci; g.Ho = H / 2; g.Wo = Wd / 2;
     g.M = (int64_t)B * g.Ho * g.Wo; g.N = Co; g.K = 4 * Ci; g.epi = EPI_BIAS; g.cls = ACX_K_DOWNSAMPLE;
     return launch_gemm(c, g, st);
@@ -414,7 +418,7 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
     ACX_TRY(launch_logmel(c, wav, B, L, p.T, feat, true, st));
     ACX_TRY(launch_stem(c, feat, B, p.T, p.Hs[0], x[0], st));
     for (int s = 0; s < 4; ++s) {
-        if (s > 0) ACX_TRY(run_downsample(c, s, x[s - 1], x[s], stats, B, p.Hs[s - 1], p.Ws[s - 1], st));
+        if (s > 0) ACX_TRY(run_downsample(c, s, x[s - 1], x[s], y, B, p.Hs[s - 1], p.Ws[s - 1], st));
         for (int j = 0; j < kDepths[s]; ++j) ACX_TRY(run_block(c, s, j, x[s], y, hidden, stats, B, p.Hs[s], p.Ws[s], st));
     }
     if (mode == ACX_MODE_FRAME) return launch_nhwc_to_nchw(c, x[3], out0, B, p.Hs[3], p.Ws[3], kDims[3], st);
@@ -452,7 +456,7 @@ int acx_block_mlp(acx_ctx* c, int stage, int block, const float* y, const float*
     const BlockW& bw = c->blocks[stage][block];
     const int64_t M = (int64_t)B * H * Wd;
     GemmArgs g1{};
-    g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.M = M; g1.N = 4 * C; g1.K = C;
+    g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.colsum = bw.w1sum; g1.M = M; g1.N = 4 * C; g1.K = C;
     g1.epi = EPI_GELU; g1.cls = ACX_K_PW1;
     ACX_TRY(launch_gemm(c, g1, (hipStream_t)stream));
     GemmArgs g2{};
@@ -484,12 +488,12 @@ int acx_block(acx_ctx* c, int stage, int block, float* x, int B, int H, int Wd, 
     return run_block(c, stage, block, x, y, hidden, stats, B, H, Wd, (hipStream_t)stream);
 }
 
-int acx_downsample(acx_ctx* c, int i, const float* x, float* out, float* stats, int B, int H, int Wd, void* stream) {
+int acx_downsample(acx_ctx* c, int i, const float* x, float* out, float* scratch, int B, int H, int Wd, void* stream) {
     ACX_TRY(need_ready(c));
     if (i < 1 || i > 3) ACX_FAIL(ACX_ERR_ARG, "acx_downsample: layer index %d (expected 1..3)", i);
-    if (!x || !out || !stats || B <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_downsample: bad argument");
+    if (!x || !out || !scratch || B <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_downsample: bad argument");
     if (H < 2 || Wd < 2) ACX_FAIL(ACX_ERR_SHAPE, "acx_downsample: kernel size can't be greater than actual input size (%dx%d)", H, Wd);
-    return run_downsample(c, i, x, out, stats, B, H, Wd, (hipStream_t)stream);
+    return run_downsample(c, i, x, out, scratch, B, H, Wd, (hipStream_t)stream);
 }
 
 int acx_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs, void* stream) {

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
 // Per-row LayerNorm statistics over C channels (biased variance, eps inside the sqrt --
 // convnext.py:537-540 / F.layer_norm): stats[row] = (mean, rstd).  G = C/12 lanes per row, each
 // lane holds 3 float4; reductions are xor-shuffles inside the G-lane group (G = 8..64).
-template <int G>
+// NORMALIZE: write (x - mean) * rstd instead (input of the downsample convs, convnext.py:230-235).
+template <int G, bool NORMALIZE>
 __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                        long long rows, float eps) {
     constexpr int C = G * 12;
@@ -131,25 +132,44 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__
 #pragma unroll
         for (int o = G / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
         const float rstd = 1.0f / sqrtf(d * (1.0f / C) + eps);
-        if (valid && g == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mean, rstd);
+        if (NORMALIZE) {      // `stats` is the (rows, C) output: (x - mean) * rstd, affine folded downstream
+            if (valid) {
+                float4* o = reinterpret_cast<float4*>(stats + row * C);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    o[g + G * k] = make_float4((v[k].x - mean) * rstd, (v[k].y - mean) * rstd,
+                                               (v[k].z - mean) * rstd, (v[k].w - mean) * rstd);
+            }
+        } else if (valid && g == 0) {
+            *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mean, rstd);
+        }
     }
 }
 
-int launch_rowstats(acx_ctx* c, const float* x, float* stats, int64_t M, int C, hipStream_t s) {
+template <bool NORMALIZE>
+static int launch_rows(acx_ctx* c, const float* x, float* out, int64_t M, int C, hipStream_t s) {
     const int G = C / 12;
     long long blocks = (M + (256 / G) - 1) / (256 / G);
     if (blocks > 16384) blocks = 16384;
     ProfScope ps(c, ACX_K_ROWSTATS, s);
     dim3 grid((unsigned)blocks), blk(256);
     switch (C) {
-        case 96: rowstats_kernel<8><<<grid, blk, 0, s>>>(x, stats, M, 1e-6f); break;
-        case 192: rowstats_kernel<16><<<grid, blk, 0, s>>>(x, stats, M, 1e-6f); break;
-        case 384: rowstats_kernel<32><<<grid, blk, 0, s>>>(x, stats, M, 1e-6f); break;
-        case 768: rowstats_kernel<64><<<grid, blk, 0, s>>>(x, stats, M, 1e-6f); break;
+        case 96: rowstats_kernel<8, NORMALIZE><<<grid, blk, 0, s>>>(x, out, M, 1e-6f); break;
+        case 192: rowstats_kernel<16, NORMALIZE><<<grid, blk, 0, s>>>(x, out, M, 1e-6f); break;
+        case 384: rowstats_kernel<32, NORMALIZE><<<grid, blk, 0, s>>>(x, out, M, 1e-6f); break;
+        case 768: rowstats_kernel<64, NORMALIZE><<<grid, blk, 0, s>>>(x, out, M, 1e-6f); break;
         default: ACX_FAIL(ACX_ERR_SHAPE, "rowstats: unsupported channel count %d", C);
     }
     ACX_HIP(hipGetLastError());
     return ACX_OK;
+}
+
+int launch_rowstats(acx_ctx* c, const float* x, float* stats, int64_t M, int C, hipStream_t s) {
+    return launch_rows<false>(c, x, stats, M, C, s);
+}
+
+int launch_layernorm_rows(acx_ctx* c, const float* x, float* out, int64_t M, int C, hipStream_t s) {
+    return launch_rows<true>(c, x, out, M, C, s);
 }
 
 template <int TW, int TH>

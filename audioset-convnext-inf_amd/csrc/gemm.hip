@@ -1,18 +1,22 @@
 // K4/K5 -- the dense contractions of the backbone on the f32-input matrix cores
 // (v_mfma_f32_32x32x2_f32: exact fp32 products, k-ordered fp32 accumulation):
-//   pwconv1 + GELU   (Block.pwconv1 / act,  convnext.py:62-65, :79-80)   A = LayerNorm(y)
-//   pwconv2 + gamma + residual (convnext.py:66-71, :81-86)               A = hidden
-//   downsample 2x2/s2 conv as a GEMM over K = 4C (convnext.py:230-235)   A = LayerNorm(x) gathered
-// out[M,N] = epi( A'[M,K] . Wt[N,K]^T + bias[N] ),  A' = (A - mean_row) * rstd_row when stats are
-// given (the LayerNorm affine is folded into Wt/bias at acx_finalize).
+//   pwconv1 + GELU   (Block.norm / pwconv1 / act, convnext.py:61-65, :78-80)   A = y (dwconv output)
+//   pwconv2 + gamma + residual (convnext.py:66-71, :81-86)                     A = hidden
+//   downsample 2x2/s2 conv as a GEMM over K = 4C (convnext.py:230-235)         A = LayerNorm(x), gathered
+// out[M,N] = epi( A[M,K] . Wt[N,K]^T ).
 //
-// Tiling: 128 x BN x 32 per workgroup, 4 waves; each wave owns TM x TN tiles of 32x32 and steps K by
-// 2 per MFMA.  Operand fragments are read from LDS as one ds_read_b128 per 4 k-steps: lane half h
-// takes floats [8g+4h, 8g+4h+4) of its row, so MFMA j of group g contracts k = {8g+j, 8g+4+j};
-// A and B use the same permutation, which leaves the sum unchanged.  LDS rows are padded to 36
-// floats: the 16-lane groups of ds_read_b128 then hit 16 distinct 4-bank slots (conflict-free).
-// Global->LDS staging goes through registers (next tile's loads are issued before the MFMAs of the
-// current one) because the A path applies LayerNorm / the 2x2 gather on the way.
+// LayerNorm in front of pwconv1 is applied in the EPILOGUE: with the affine folded into Wt/bias
+// (acx_finalize) LN(y).Wt^T = rstd_m * (y.Wt^T - mean_m * colsum_n), colsum_n = sum_k Wt[n][k].  That keeps
+// BOTH operands plain copies, so both are staged global -> LDS by LDS-DMA (global_load_lds_dwordx4): no
+// staging VGPRs, no ds_write pass, no VALU in the load path (the register-staged version of this kernel
+// spent 15 % of its time there -- profiles/r01_gemm_lab.txt).
+//
+// Tiling: 128 x BN x 32 per workgroup, 4 waves, each wave TM x TN tiles of 32x32, K stepped by 2 per
+// MFMA.  LDS tile image: [row][8 chunks of 16 B] with 128-B rows (LDS-DMA writes wave-linear 1-KB
+// pieces, so rows cannot be padded); bank conflicts are removed by an XOR swizzle applied on the per-lane
+// SOURCE address and again on the fragment read: position p of row r holds global chunk p ^ ((r>>1)&7).
+// A fragment read is one ds_read_b128 per 4 k-steps: lane half h takes chunk 2g+h of its row, so MFMA j
+// of group g contracts k = {8g+j, 8g+4+j} (A and B use the same permutation).
 #include "acx_internal.h"
 
 namespace acx {
@@ -22,51 +26,54 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBM = 128;
 constexpr int kBK = 32;
-constexpr int kLdsStride = kBK + 4;
+constexpr int kRowBytes = kBK * 4;        // 128-B LDS rows
 
-__device__ __forceinline__ float erf_as(float x) {
-    // Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 (fp32 erf itself carries ~1e-7)
-    const float ax = fabsf(x);
-    const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __expf(-ax * ax);
-    const float y = fmaf(-p * t, e, 1.0f);
-    return copysignf(y, x);
-}
-
-__device__ __forceinline__ float gelu_erf(float x) {   // nn.GELU() default (approximate='none')
-    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+// nn.GELU() default (approximate='none'): 0.5 v (1 + erf(v / sqrt 2)), with erf from Abramowitz-Stegun
+// 7.1.26 (|erf error| <= 1.5e-7, so |gelu error| <= 0.75e-7 |v|):
+//   erf(u) = sign(u) (1 - q),  q = (a1 t + ... + a5 t^5) exp(-u^2),  t = 1 / (1 + p |u|)
+//   gelu(v) = max(v, 0) - 0.5 |v| q          (since v sign(v) = |v|)
+// 14 VALU per element, two of them transcendental (v_rcp_f32, v_exp_f32).
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float av = fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678f, av, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(v * v * -0.72134752f);      // exp(-v^2 / 2)
+    const float q = pl * t * e;
+    return fmaf(-0.5f * av, q, fmaxf(v, 0.0f));
 }
 
 struct GemmParams {
-    const float* A; const float* Wt; const float* bias; float* out; const float* stats; const float* resid;
+    const float* A; const float* Wt; const float* bias; float* out;
+    const float* stats;       // EPI_GELU: (M,2) mean/rstd of the A rows
+    const float* colsum;      // EPI_GELU: (N) sum_k Wt[n][k]
+    const float* resid;       // EPI_RESID
     long long M; int N; int K;
-    int H, W, C, Ho, Wo;      // gather mode
+    int H, W, C, Ho, Wo;      // gather mode (A is NHWC (B,H,W,C); row m = (b,ho,wo); k = (dy*2+dx)*C + c)
     int tiles_n;
 };
 
-// AMODE: 0 plain rows, 1 rows + LayerNorm, 2 2x2 gather + LayerNorm
-//
-// Pipeline per 32-deep k-tile (LDS double-buffered, ONE barrier per tile):
-//   issue the global loads of tile t+1 into registers (raw)      -- latency hides under the MFMAs
-//   64 MFMAs per wave on tile t from LDS buffer t&1
-//   LayerNorm the staged registers, write them to LDS buffer (t+1)&1, barrier
-template <int BN, int WM, int WN, int EPI, int AMODE>
+__device__ __forceinline__ void lds_dma16(const float* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// GATHER: 0 plain rows, 1 2x2 patch gather (downsample)
+template <int BN, int WM, int WN, int EPI, int GATHER>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int TM = kBM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
-    constexpr int A_F4 = kBM * kBK / 4 / 256;     // float4 per thread per tile (4)
-    constexpr int B_F4 = BN * kBK / 4 / 256;      // 4 (BN=128) or 3 (BN=96)
-    constexpr int A_TILE = kBM * kLdsStride, B_TILE = BN * kLdsStride;
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    float* As = smem_f;                  // [2][A_TILE]
-    float* Bs = smem_f + 2 * A_TILE;     // [2][B_TILE]
+    constexpr int A_TILE = kBM * kRowBytes, B_TILE = BN * kRowBytes;     // bytes
+    constexpr int A_DMA = kBM / 32, B_DMA = BN / 32;                     // 1-KB pieces per wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                   // [2][A_TILE]
+    char* Bs = smem + 2 * A_TILE;      // [2][B_TILE]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int tile_n = blockIdx.x % p.tiles_n;
@@ -74,73 +81,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const long long m0 = tile_m * kBM;
     const int n0 = tile_n * BN;
 
-    // ---- per-thread staging coordinates -------------------------------------------------------
-    const int c4 = tid & 7;           // which float4 of the 32-float k-slab
-    const int r0 = tid >> 3;          // row within a 32-row group
-    const float* a_ptr[A_F4];
-    float2 a_st[A_F4];                // (mean, rstd) of the row (AMODE 1)
-    long long a_pix[A_F4];            // AMODE 2: top-left input pixel of the 2x2 patch
+    // ---- LDS-DMA source pointers: wave w stages rows [R*w, R*w+R) of each tile, 8 rows per piece ------
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const float* a_src[A_DMA];
 #pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-        long long m = m0 + r0 + 32 * i;
+    for (int i = 0; i < A_DMA; ++i) {
+        const int row = A_DMA * 8 * wave + 8 * i + prow;
+        const int chunk = pchunk ^ ((row >> 1) & 7);
+        long long m = m0 + row;
         if (m >= p.M) m = p.M - 1;
-        a_st[i] = make_float2(0.f, 1.f);
-        a_pix[i] = 0;
-        a_ptr[i] = p.A;
-        if (AMODE == 2) {
+        if (GATHER) {
             const int wo = (int)(m % p.Wo);
             const long long t = m / p.Wo;
             const int ho = (int)(t % p.Ho);
             const long long b = t / p.Ho;
-            a_pix[i] = (b * p.H + 2 * ho) * p.W + 2 * wo;
+            a_src[i] = p.A + ((b * p.H + 2 * ho) * p.W + 2 * wo) * p.C + 4 * chunk;
         } else {
-            a_ptr[i] = p.A + m * p.K + 4 * c4;
-            if (AMODE == 1) a_st[i] = *reinterpret_cast<const float2*>(p.stats + 2 * m);
+            a_src[i] = p.A + m * p.K + 4 * chunk;
         }
     }
-    const float* b_ptr = p.Wt + (long long)(n0 + r0) * p.K + 4 * c4;
-    const long long b_step = 32LL * p.K;
-
-    // Staged tile registers are NAMED scalars on purpose: as arrays hipcc (ROCm 7.2) leaves them in
-    // scratch memory (un-promoted alloca) once a sched_barrier sits between their def and use.
-    f32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    float2 rs0, rs1, rs2, rs3;
-    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = f32x4{0.f, 0.f, 0.f, 0.f};
-    rs0 = rs1 = rs2 = rs3 = make_float2(0.f, 1.f);
-#define ACX_LOAD_A(i, k0)                                                                              \
-    if (AMODE == 2) {                                                                                  \
-        const int qd = (k0) / p.C;                                                                     \
-        const int cc = (k0) - qd * p.C;                                                                \
-        const long long pix = a_pix[i] + (long long)(qd >> 1) * p.W + (qd & 1);                        \
-        ra##i = *reinterpret_cast<const f32x4*>(p.A + pix * p.C + cc + 4 * c4);                       \
-        rs##i = *reinterpret_cast<const float2*>(p.stats + 2 * pix);                                   \
-    } else {                                                                                           \
-        ra##i = *reinterpret_cast<const f32x4*>(a_ptr[i] + (k0));                                     \
-        rs##i = a_st[i];                                                                               \
+    const float* b_src[B_DMA];
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i) {
+        const int row = B_DMA * 8 * wave + 8 * i + prow;
+        const int chunk = pchunk ^ ((row >> 1) & 7);
+        b_src[i] = p.Wt + (long long)(n0 + row) * p.K + 4 * chunk;
     }
-#define ACX_LOAD_B(i, k0) \
-    if (i < B_F4) rb##i = *reinterpret_cast<const f32x4*>(b_ptr + i * b_step + (k0));
-#define ACX_LOAD_TILE(k0)                                                                              \
+    char* a_dst = As + A_DMA * 8 * wave * kRowBytes;
+    char* b_dst = Bs + B_DMA * 8 * wave * kRowBytes;
+#define ACX_DMA_TILE(k0, buf)                                                                          \
     {                                                                                                  \
-        ACX_LOAD_A(0, k0) ACX_LOAD_A(1, k0) ACX_LOAD_A(2, k0) ACX_LOAD_A(3, k0)                        \
-        ACX_LOAD_B(0, k0) ACX_LOAD_B(1, k0) ACX_LOAD_B(2, k0) ACX_LOAD_B(3, k0)                        \
+        long long koff = (k0);                                                                         \
+        if (GATHER) {                                                                                  \
+            const int qd = (k0) / p.C;                                                                 \
+            koff = (long long)((qd >> 1) * p.W + (qd & 1)) * p.C + ((k0) - qd * p.C);                  \
+        }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < A_DMA; ++i)                                              \
+            lds_dma16(a_src[i] + koff, a_dst + (buf) * A_TILE + i * 8 * kRowBytes);                    \
+        _Pragma("unroll") for (int i = 0; i < B_DMA; ++i)                                              \
+            lds_dma16(b_src[i] + (k0), b_dst + (buf) * B_TILE + i * 8 * kRowBytes);                    \
     }
-#define ACX_STORE_A(i, as_)                                                                            \
-    {                                                                                                  \
-        f32x4 v = ra##i;                                                                               \
-        if (AMODE != 0) v = (v - rs##i.x) * rs##i.y;                                                   \
-        *reinterpret_cast<f32x4*>(&(as_)[(r0 + 32 * i) * kLdsStride + 4 * c4]) = v;                    \
-    }
-#define ACX_STORE_B(i, bs_) \
-    if (i < B_F4) *reinterpret_cast<f32x4*>(&(bs_)[(r0 + 32 * i) * kLdsStride + 4 * c4]) = rb##i;
-#define ACX_STORE_TILE(buf)                                                                            \
-    {                                                                                                  \
-        float* as_ = As + (buf) * A_TILE;                                                              \
-        float* bs_ = Bs + (buf) * B_TILE;                                                              \
-        ACX_STORE_A(0, as_) ACX_STORE_A(1, as_) ACX_STORE_A(2, as_) ACX_STORE_A(3, as_)                \
-        ACX_STORE_B(0, bs_) ACX_STORE_B(1, bs_) ACX_STORE_B(2, bs_) ACX_STORE_B(3, bs_)                \
-    }
-    static_assert(A_F4 == 4 && B_F4 <= 4, "staging macros assume 4 A rows and <= 4 B rows per thread");
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -150,79 +130,138 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / kBK;
-    ACX_LOAD_TILE(0);
-    ACX_STORE_TILE(0);
-    __syncthreads();
-    const int a_frag_off = (wm * TM * 32 + l31) * kLdsStride + 4 * hh;
-    const int b_frag_off = (wn * TN * 32 + l31) * kLdsStride + 4 * hh;
-#define ACX_COMPUTE_TILE(buf)                                                                          \
+    // fragment read offsets (bytes) inside a tile: row l31 of the wave's 32-row tile, chunk (2g+hh)^sw
+    const int sw = (l31 >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) foff[g] = l31 * kRowBytes + (((2 * g + hh) ^ sw) << 4);
+    const int a_frag_off = wm * TM * 32 * kRowBytes;
+    const int b_frag_off = wn * TN * 32 * kRowBytes;
+#define ACX_READ_FRAGS(af_, bf_, abase, bbase, g)                                                      \
     {                                                                                                  \
-        const float* a_frag_base = As + (buf) * A_TILE + a_frag_off;                                   \
-        const float* b_frag_base = Bs + (buf) * B_TILE + b_frag_off;                                   \
-        _Pragma("unroll") for (int g = 0; g < kBK / 8; ++g) {                                          \
-            float4 af[TM], bf[TN];                                                                     \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
-                af[i] = *reinterpret_cast<const float4*>(a_frag_base + i * 32 * kLdsStride + 8 * g);   \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
-                bf[j] = *reinterpret_cast<const float4*>(b_frag_base + j * 32 * kLdsStride + 8 * g);   \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                           \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0); \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0); \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0); \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0); \
-            }                                                                                          \
-        }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+            af_[i] = *reinterpret_cast<const f32x4*>((abase) + i * 32 * kRowBytes + foff[g]);          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+            bf_[j] = *reinterpret_cast<const f32x4*>((bbase) + j * 32 * kRowBytes + foff[g]);          \
+    }
+#define ACX_MFMA_GROUP(af_, bf_)                                                                       \
+    {                                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[i][e], bf_[j][e], acc[i][j], 0, 0, 0); \
+    }
+    static_assert(kBK == 32, "the tile schedule below is written for 4 k-groups of 8");
+
+    const int nk = p.K / kBK;
+    ACX_DMA_TILE(0, 0);
+    __syncthreads();          // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+    // Software pipeline over k-tiles, ONE barrier per tile, placed BEFORE the last MFMA group so that
+    // every wave leaves it with 4*TM*TN MFMAs already fed (barrier skew and the first LDS reads of the
+    // next tile hide under them); fragments are double-buffered in registers so LDS latency never stalls
+    // a wave inside a tile:
+    //   DMA(t+1) | MFMA g0 | rd g2 | MFMA g1 | rd g3 | MFMA g2 | barrier | rd g0(t+1) | MFMA g3 | rd g1(t+1)
+    f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+    {
+        const char* ab = As + a_frag_off;
+        const char* bb = Bs + b_frag_off;
+        ACX_READ_FRAGS(af0, bf0, ab, bb, 0)
+        ACX_READ_FRAGS(af1, bf1, ab, bb, 1)
     }
     for (int kt = 0; kt + 1 < nk; ++kt) {
-        ACX_LOAD_TILE((kt + 1) * kBK);
-        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMAs (hipcc sinks it otherwise)
-        ACX_COMPUTE_TILE(kt & 1);
+        const char* ab = As + (kt & 1) * A_TILE + a_frag_off;
+        const char* bb = Bs + (kt & 1) * B_TILE + b_frag_off;
+        const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
+        const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
+#ifndef ACX_LAB_NO_GLOBAL
+        ACX_DMA_TILE((kt + 1) * kBK, (kt + 1) & 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
-        // opaque re-definition: pins the LayerNorm math and the vmcnt wait BELOW the MFMA block
-        asm volatile("" : "+v"(ra0), "+v"(ra1), "+v"(ra2), "+v"(ra3), "+v"(rb0), "+v"(rb1), "+v"(rb2), "+v"(rb3));
-        ACX_STORE_TILE((kt + 1) & 1);
+        ACX_MFMA_GROUP(af0, bf0)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_READ_FRAGS(af0, bf0, ab, bb, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af1, bf1)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_READ_FRAGS(af1, bf1, ab, bb, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af0, bf0)
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        ACX_READ_FRAGS(af0, bf0, abn, bbn, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af1, bf1)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_READ_FRAGS(af1, bf1, abn, bbn, 1)
     }
-    ACX_COMPUTE_TILE((nk - 1) & 1);
-#undef ACX_COMPUTE_TILE
-#undef ACX_LOAD_TILE
-#undef ACX_STORE_TILE
-#undef ACX_LOAD_A
-#undef ACX_LOAD_B
-#undef ACX_STORE_A
-#undef ACX_STORE_B
+    {
+        const char* ab = As + ((nk - 1) & 1) * A_TILE + a_frag_off;
+        const char* bb = Bs + ((nk - 1) & 1) * B_TILE + b_frag_off;
+        ACX_MFMA_GROUP(af0, bf0)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_READ_FRAGS(af0, bf0, ab, bb, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af1, bf1)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_READ_FRAGS(af1, bf1, ab, bb, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af0, bf0)
+        ACX_MFMA_GROUP(af1, bf1)
+    }
+#undef ACX_DMA_TILE
+#undef ACX_READ_FRAGS
+#undef ACX_MFMA_GROUP
 
     // ---- epilogue: D tile layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) -----
+#ifdef ACX_LAB_NO_EPI      // diagnostic (tools/gemm_lab.hip): main loop only
+    {
+        float t = 0.f;
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) p.out[tid] = t;
+        return;
+    }
+#endif
     const bool full = m0 + kBM <= p.M;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + l31;
-        const float bn = p.bias[n];
+    for (int i = 0; i < TM; ++i) {
+        const long long mb = m0 + (wm * TM + i) * 32 + 4 * hh;
+        float2 st[16];
+        if (EPI == EPI_GELU) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const long long mb = m0 + (wm * TM + i) * 32 + 4 * hh;
+            for (int r = 0; r < 16; ++r) {
+                long long m = mb + (r & 3) + 8 * (r >> 2);
+                if (m >= p.M) m = p.M - 1;
+                st[r] = *reinterpret_cast<const float2*>(p.stats + 2 * m);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + l31;
+            const float bn = p.bias[n];
+            const float cs = (EPI == EPI_GELU) ? p.colsum[n] : 0.f;
             float* op = p.out + mb * p.N + n;
             const float* rp = (EPI == EPI_RESID) ? p.resid + mb * p.N + n : nullptr;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = acc[i][j][r];
+                if (EPI == EPI_GELU) v[r] = gelu_erf(fmaf(st[r].y, fmaf(-st[r].x, cs, v[r]), bn));
+                else v[r] += bn;
+            }
             if (full) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const long long off = (long long)((r & 3) + 8 * (r >> 2)) * p.N;
-                    float v = acc[i][j][r] + bn;
-                    if (EPI == EPI_GELU) v = gelu_erf(v);
-                    if (EPI == EPI_RESID) v += rp[off];
-                    op[off] = v;
+                    op[off] = (EPI == EPI_RESID) ? v[r] + rp[off] : v[r];
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
                     if (mb + dr < p.M) {
-                        float v = acc[i][j][r] + bn;
-                        if (EPI == EPI_GELU) v = gelu_erf(v);
-                        if (EPI == EPI_RESID) v += rp[(long long)dr * p.N];
-                        op[(long long)dr * p.N] = v;
+                        const long long off = (long long)dr * p.N;
+                        op[off] = (EPI == EPI_RESID) ? v[r] + rp[off] : v[r];
                     }
                 }
             }
@@ -231,9 +270,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 }
 
 template <int BN>
-constexpr size_t gemm_lds_bytes() { return (size_t)2 * (kBM + BN) * kLdsStride * sizeof(float); }
+constexpr size_t gemm_lds_bytes() { return (size_t)2 * (kBM + BN) * kRowBytes; }
 
-template <int BN, int WM, int WN, int EPI, int AMODE>
+template <int BN, int WM, int WN, int EPI, int GATHER>
 static int launch_cfg(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_n = p.N / BN;
@@ -242,19 +281,19 @@ static int launch_cfg(const GemmParams& p0, hipStream_t s) {
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm: grid too large");
     static bool attr_set = false;
     if (!attr_set) {
-        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BN, WM, WN, EPI, AMODE>),
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BN, WM, WN, EPI, GATHER>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<BN>()));
         attr_set = true;
     }
-    gemm_f32_kernel<BN, WM, WN, EPI, AMODE><<<dim3((unsigned)blocks), dim3(256), gemm_lds_bytes<BN>(), s>>>(p);
+    gemm_f32_kernel<BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(256), gemm_lds_bytes<BN>(), s>>>(p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
 
-template <int EPI, int AMODE>
+template <int EPI, int GATHER>
 static int launch_bn(const GemmParams& p, hipStream_t s) {
-    if (p.N % 128 == 0) return launch_cfg<128, 2, 2, EPI, AMODE>(p, s);
-    if (p.N % 96 == 0) return launch_cfg<96, 4, 1, EPI, AMODE>(p, s);
+    if (p.N % 128 == 0) return launch_cfg<128, 2, 2, EPI, GATHER>(p, s);
+    if (p.N % 96 == 0) return launch_cfg<96, 4, 1, EPI, GATHER>(p, s);
     ACX_FAIL(ACX_ERR_SHAPE, "gemm: N=%d is not a multiple of 96 or 128", p.N);
 }
 
@@ -262,19 +301,21 @@ int launch_gemm(acx_ctx* c, const GemmArgs& a, hipStream_t s) {
     if (a.K % kBK != 0) ACX_FAIL(ACX_ERR_SHAPE, "gemm: K=%d is not a multiple of %d", a.K, kBK);
     if (a.M <= 0) return ACX_OK;
     GemmParams p;
-    p.A = a.A; p.Wt = a.Wt; p.bias = a.bias; p.out = a.out; p.stats = a.stats; p.resid = a.resid;
+    p.A = a.A; p.Wt = a.Wt; p.bias = a.bias; p.out = a.out; p.stats = a.stats; p.colsum = a.colsum; p.resid = a.resid;
     p.M = a.M; p.N = a.N; p.K = a.K; p.H = a.H; p.W = a.W; p.C = a.C; p.Ho = a.Ho; p.Wo = a.Wo;
     p.tiles_n = 0;
     ProfScope ps(c, a.cls, s);
     if (a.gather) {
-        if (!a.stats || a.epi != EPI_BIAS || a.C % kBK != 0) ACX_FAIL(ACX_ERR_ARG, "gemm: bad gather configuration");
-        return launch_bn<EPI_BIAS, 2>(p, s);
+        if (a.epi != EPI_BIAS || a.C % kBK != 0) ACX_FAIL(ACX_ERR_ARG, "gemm: bad gather configuration");
+        return launch_bn<EPI_BIAS, 1>(p, s);
     }
-    if (a.epi == EPI_GELU && a.stats) return launch_bn<EPI_GELU, 1>(p, s);
-    if (a.epi == EPI_RESID && !a.stats) return launch_bn<EPI_RESID, 0>(p, s);
-    if (a.epi == EPI_BIAS && !a.stats) return launch_bn<EPI_BIAS, 0>(p, s);
-    ACX_FAIL(ACX_ERR_ARG, "gemm: unsupported epilogue/prologue combination (epi=%d, stats=%d)", a.epi,
-             a.stats != nullptr);
+    if (a.epi == EPI_GELU) {
+        if (!a.stats || !a.colsum) ACX_FAIL(ACX_ERR_ARG, "gemm: the LayerNorm+GELU epilogue needs row stats and column sums");
+        return launch_bn<EPI_GELU, 0>(p, s);
+    }
+    if (a.epi == EPI_RESID) return launch_bn<EPI_RESID, 0>(p, s);
+    if (a.epi == EPI_BIAS) return launch_bn<EPI_BIAS, 0>(p, s);
+    ACX_FAIL(ACX_ERR_ARG, "gemm: unknown epilogue %d", a.epi);
 }
 
 }  // namespace acx

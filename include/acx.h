@@ -83,8 +83,8 @@ ACX_API int acx_set_weight(acx_ctx* ctx, const char* state_dict_key, const float
  *   STFT buffers are hann x DFT (else ACX_ERR_UNSUPPORTED) so that the FFT kernel may stand in
  *   for the two Conv1d (convnext.py:179-187,298);
  *   dwconv (C,1,7,7) -> [49][C]; LayerNorm affine of each block folded into pwconv1;
- *   gamma folded into pwconv2 (convnext.py:78-83); downsample conv (C',C,2,2) -> [C'][4C];
- *   head padded to 544 rows.
+ *   gamma folded into pwconv2 (convnext.py:78-83); downsample conv (C',C,2,2) -> [C'][4C] with its
+ *   LayerNorm affine folded in.
  * May be called again after weights change. */
 ACX_API int acx_finalize(acx_ctx* ctx);
 
@@ -124,8 +124,9 @@ ACX_API int acx_block(acx_ctx* ctx, int stage, int block, float* x, int B, int H
               size_t scratch_bytes, void* stream);
 ACX_API int acx_block_scratch_bytes(int stage, int B, int H, int W, size_t* out_bytes);
 /* K5: downsample_layers[i], i=1..3: LayerNorm + Conv2d 2x2 s2 (convnext.py:230-235).
- * x NHWC (B,H,W,C_{i-1}) -> out NHWC (B,H/2,W/2,C_i); stats scratch (B*H*W,2). */
-ACX_API int acx_downsample(acx_ctx* ctx, int i, const float* x, float* out, float* stats, int B, int H,
+ * x NHWC (B,H,W,C_{i-1}) -> out NHWC (B,H/2,W/2,C_i); scratch (B*H*W*C_{i-1}) fp32 receives the
+ * normalised copy of x that the 2x2 gather GEMM reads. */
+ACX_API int acx_downsample(acx_ctx* ctx, int i, const float* x, float* out, float* scratch, int B, int H,
                    int W, void* stream);
 /* K6: pooling + final LayerNorm + head + sigmoid (convnext.py:279-285,321-325).
  * x NHWC (B,H3,7,768). Any of scene/logits/probs may be NULL. */
