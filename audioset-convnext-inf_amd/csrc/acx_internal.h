@@ -55,6 +55,7 @@ struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layou
     float* w1sum = nullptr;  // [4C]      sum_k w1[n][k]  (LayerNorm applied in the GEMM epilogue)
     float* w2 = nullptr;     // [C][4C]   gamma * pwconv2
     float* b2 = nullptr;     // [C]       gamma * pwconv2 bias
+    float* wpack = nullptr;  // [4C/32][64*C]  per hidden chunk: w1 rows [32][C] then w2 columns [C][32] (fused MLP)
 };
 
 struct DownW {           // downsample_layers[i], i>=1 (convnext.py:230-235)
@@ -99,6 +100,7 @@ struct acx_ctx {
     float* d_head_w = nullptr;    // [527][768]
     float* d_head_b = nullptr;    // [527]
 
+    bool use_fused_mlp = true;    // ACX_DISABLE_FUSED_MLP=1 turns the fused stage-0/1 MLP kernel off
     acx::Profile prof;
 };
 
@@ -133,6 +135,9 @@ struct GemmArgs {
     int epi; int cls;
 };
 int launch_gemm(acx_ctx* c, const GemmArgs& a, hipStream_t s);
+bool mlp_fused_supported(int C);
+// x += MLP(LN(y)) for one block, hidden activation kept in registers (mlp_fused.hip)
+int launch_mlp_fused(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s);
 int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
                      hipStream_t s);
 int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, int W, int C, hipStream_t s);

@@ -2,6 +2,7 @@
 // forward orchestration.  See include/acx.h for the contract and the reference interfaces each
 // entry point stands in for.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "acx_internal.h"
@@ -127,6 +128,10 @@ static int finalize_impl(acx_ctx* c) {
     }
     ACX_HIP(hipSetDevice(c->device));
     free_device(c);
+    {
+        const char* e = std::getenv("ACX_DISABLE_FUSED_MLP");
+        c->use_fused_mlp = !(e && e[0] == '1');
+    }
 
     // ---- frontend ---------------------------------------------------------------------------
     std::vector<float> hann;
@@ -233,6 +238,19 @@ static int finalize_impl(acx_ctx* c) {
             }
             ACX_TRY(upload(c, f2, &bw.w2));
             ACX_TRY(upload(c, fb2, &bw.b2));
+            if (mlp_fused_supported(C)) {       // chunk-major image for the fused kernel's LDS-DMA
+                const int nch = 4 * C / 32;
+                std::vector<float> pk((size_t)nch * 64 * C);
+                for (int j = 0; j < nch; ++j) {
+                    float* blk = pk.data() + (size_t)j * 64 * C;
+                    for (int r = 0; r < 32; ++r)
+                        for (int k = 0; k < C; ++k) blk[(size_t)r * C + k] = f1[(size_t)(32 * j + r) * C + k];
+                    float* blk2 = blk + (size_t)32 * C;
+                    for (int ch = 0; ch < C; ++ch)
+                        for (int h = 0; h < 32; ++h) blk2[(size_t)ch * 32 + h] = f2[(size_t)ch * 4 * C + 32 * j + h];
+                }
+                ACX_TRY(upload(c, pk, &bw.wpack));
+            }
             c->blocks[s].push_back(bw);
         }
     }
@@ -278,6 +296,10 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     const int C = kDims[s];
     const BlockW& bw = c->blocks[s][j];
     const int64_t M = (int64_t)B * H * Wd;
+    if (c->use_fused_mlp && mlp_fused_supported(C)) {
+        ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));      // LN statistics are computed in-kernel
+        return launch_mlp_fused(c, bw, C, y, x, M, st);
+    }
     ACX_TRY(launch_dwconv(c, bw, C, x, y, stats, B, H, Wd, st));
     GemmArgs g1{};
     g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.colsum = bw.w1sum; g1.M = M; g1.N = 4 * C; g1.K = C;
@@ -455,6 +477,7 @@ int acx_block_mlp(acx_ctx* c, int stage, int block, const float* y, const float*
     const int C = kDims[stage];
     const BlockW& bw = c->blocks[stage][block];
     const int64_t M = (int64_t)B * H * Wd;
+    if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused(c, bw, C, y, x, M, (hipStream_t)stream);
     GemmArgs g1{};
     g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.colsum = bw.w1sum; g1.M = M; g1.N = 4 * C; g1.K = C;
     g1.epi = EPI_GELU; g1.cls = ACX_K_PW1;

@@ -38,8 +38,12 @@ MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA, dense (no xf32 on gfx950)
 DIMS, DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
 
 
+FUSED_STAGES = (0, 1) if os.environ.get("ACX_DISABLE_FUSED_MLP", "0") != "1" else ()
+
+
 def algorithmic_work(B, L):
-    """Per kernel class: (total FLOPs, total algorithmic HBM bytes) of ONE forward."""
+    """Per kernel class: (total FLOPs, total algorithmic HBM bytes) of ONE forward.
+    Stages 0-1 run the fused MLP kernel (hidden activation stays on chip), stages 2-3 the two GEMMs."""
     T = L // 320 + 1
     hs = [(T + 4) // 4 + 1]
     ws = [56]
@@ -55,11 +59,15 @@ def algorithmic_work(B, L):
         n = DEPTHS[s]
         work["dwconv"][0] += n * 2.0 * 49 * pix[s] * C
         work["dwconv"][1] += n * 2.0 * pix[s] * C * 4                      # read x, write y
-        work["rowstats"][1] += n * 1.0 * pix[s] * C * 4
-        work["pw1"][0] += n * 2.0 * pix[s] * C * 4 * C
-        work["pw1"][1] += n * (pix[s] * C * 4 + pix[s] * 4 * C * 4)        # unfused: y in, hidden out
-        work["pw2"][0] += n * 2.0 * pix[s] * C * 4 * C
-        work["pw2"][1] += n * (pix[s] * 4 * C * 4 + 2.0 * pix[s] * C * 4)  # hidden in, x in/out
+        if s in FUSED_STAGES:
+            work["mlp_fused"][0] += n * 4.0 * pix[s] * C * 4 * C
+            work["mlp_fused"][1] += n * 3.0 * pix[s] * C * 4                   # y in, x in, x out
+        else:
+            work["rowstats"][1] += n * 1.0 * pix[s] * C * 4
+            work["pw1"][0] += n * 2.0 * pix[s] * C * 4 * C
+            work["pw1"][1] += n * (pix[s] * C * 4 + pix[s] * 4 * C * 4)        # y in, hidden out
+            work["pw2"][0] += n * 2.0 * pix[s] * C * 4 * C
+            work["pw2"][1] += n * (pix[s] * 4 * C * 4 + 2.0 * pix[s] * C * 4)  # hidden in, x in/out
         if s > 0:
             work["downsample"][0] += 2.0 * pix[s] * 4 * DIMS[s - 1] * C
             work["downsample"][1] += pix[s - 1] * DIMS[s - 1] * 4 + pix[s] * C * 4
@@ -190,14 +198,19 @@ def main():
                           "tflops": flops / (ms * 1e-3) / 1e12 if flops else None,
                           "algorithmic_GBs": nbytes / (ms * 1e-3) / 1e9}
         line["kernels"] = kernels
-        dom = max(("pw1", "pw2"), key=lambda k: kernels[k]["ms_per_step"])
-        per_launch_flops = work[dom][0] / (sum(DEPTHS))
+        names = {"pw1": "gemm_f32_kernel (LayerNorm+pwconv1+GELU epilogue, stages 2-3)",
+                 "pw2": "gemm_f32_kernel (pwconv2+gamma+residual epilogue, stages 2-3)",
+                 "mlp_fused": "mlp_fused_kernel (LN+pwconv1+GELU+pwconv2+residual, stages 0-1)"}
+        dom = max((k for k in names if k in kernels), key=lambda k: kernels[k]["ms_per_step"])
+        per_launch_flops = work[dom][0] / kernels[dom]["launches_per_step"]
         avg_launch_s = kernels[dom]["ms_per_step"] * 1e-3 / kernels[dom]["launches_per_step"]
         ach = per_launch_flops / avg_launch_s / 1e12
-        line["roofline"] = {"kernel": "gemm_f32_kernel (%s)" % ("pwconv1+GELU" if dom == "pw1" else "pwconv2+residual"),
-                            "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                            "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+        line["roofline"] = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
+                            "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
                             "avg_launch_ms": avg_launch_s * 1e3, "flops_per_launch": per_launch_flops}
+        mf = sum(work[k][0] for k in names) / sum(kernels[k]["ms_per_step"] * 1e-3 for k in names if k in kernels) / 1e12
+        line["roofline_all_pointwise"] = {"bound": "mfma", "achieved": mf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                          "frac": mf / MFMA_F32_PEAK_TF}
         dw = kernels["dwconv"]
         line["roofline_dwconv"] = {"kernel": "dwconv7_kernel", "bound": "hbm", "achieved": dw["algorithmic_GBs"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dw["algorithmic_GBs"] / HBM_PEAK_GBS,

@@ -56,7 +56,7 @@ enum acx_mode {
 /* kernel classes for acx_profile_read() */
 enum acx_kernel_class {
     ACX_K_FRONTEND = 0, ACX_K_STEM, ACX_K_DWCONV, ACX_K_PW1, ACX_K_PW2, ACX_K_ROWSTATS,
-    ACX_K_DOWNSAMPLE, ACX_K_POOLHEAD, ACX_K_TRANSPOSE, ACX_K_COUNT
+    ACX_K_DOWNSAMPLE, ACX_K_POOLHEAD, ACX_K_TRANSPOSE, ACX_K_MLP_FUSED, ACX_K_COUNT
 };
 
 #define ACX_MIN_SAMPLES 7360  /* shortest clip the reference accepts (last 2x2 downsample needs H>=2) */
@@ -116,7 +116,10 @@ ACX_API int acx_stem_ln(acx_ctx* ctx, const float* in, int B, int T, float* out,
 ACX_API int acx_dwconv7(acx_ctx* ctx, int stage, int block, const float* x, float* y, float* stats, int B,
                 int H, int W, void* stream);
 /* K4: LayerNorm + pwconv1 + GELU + pwconv2 + gamma + residual (convnext.py:78-86).
- * y, stats from acx_dwconv7; x updated in place; hidden = scratch (B*H*W, 4C) fp32. */
+ * y, stats from acx_dwconv7; x updated in place; hidden = scratch (B*H*W, 4C) fp32.
+ * Stages 0-1 (C = 96, 192) run as ONE fused kernel that keeps the hidden activation in registers and
+ * computes the LayerNorm statistics itself (stats / hidden are then unused); stages 2-3 run as two
+ * MFMA GEMMs.  Set ACX_DISABLE_FUSED_MLP=1 before acx_finalize to force the two-GEMM form everywhere. */
 ACX_API int acx_block_mlp(acx_ctx* ctx, int stage, int block, const float* y, const float* stats, float* x,
                   float* hidden, int B, int H, int W, void* stream);
 /* whole Block.forward (convnext.py:74-87) on NHWC x, in place. scratch >= acx_block_scratch_bytes */
