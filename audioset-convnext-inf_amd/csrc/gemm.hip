@@ -152,6 +152,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[i][e], bf_[j][e], acc[i][j], 0, 0, 0); \
     }
     static_assert(kBK == 32, "the tile schedule below is written for 4 k-groups of 8");
+    // With an LDS-DMA in flight hipcc (ROCm 7.2) no longer emits counted lgkmcnt(N) waits, only lgkmcnt(0).
+    // An opaque use of the fragments the NEXT MFMA group needs, placed right after the current group (their
+    // reads are 4*TM*TN MFMAs old by then), puts that wait in front of the next batch of ds_reads instead of
+    // behind it, so it never covers a just-issued read.
+#define ACX_TOUCH(af_, bf_)                                                                             \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af_[i]));                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bf_[j]));                \
+    }
 
     const int nk = p.K / kBK;
     ACX_DMA_TILE(0, 0);
@@ -179,19 +188,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
         ACX_MFMA_GROUP(af0, bf0)
         __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(af1, bf1)       // see ACX_TOUCH: drain the OLD reads before issuing new ones
         ACX_READ_FRAGS(af0, bf0, ab, bb, 2)
         __builtin_amdgcn_sched_barrier(0);
         ACX_MFMA_GROUP(af1, bf1)
         __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(af0, bf0)
         ACX_READ_FRAGS(af1, bf1, ab, bb, 3)
         __builtin_amdgcn_sched_barrier(0);
         ACX_MFMA_GROUP(af0, bf0)
         __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(af1, bf1)
         __syncthreads();
         ACX_READ_FRAGS(af0, bf0, abn, bbn, 0)
         __builtin_amdgcn_sched_barrier(0);
         ACX_MFMA_GROUP(af1, bf1)
         __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(af0, bf0)
         ACX_READ_FRAGS(af1, bf1, abn, bbn, 1)
     }
     {
@@ -211,6 +224,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #undef ACX_DMA_TILE
 #undef ACX_READ_FRAGS
 #undef ACX_MFMA_GROUP
+#undef ACX_TOUCH
 
     // ---- epilogue: D tile layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) -----
 #ifdef ACX_LAB_NO_EPI      // diagnostic (tools/gemm_lab.hip): main loop only

@@ -43,22 +43,27 @@ struct FusedCfg {
     static constexpr int kThreads = kWaves * 64;
     static constexpr int kPix = kWaves * 32;                 // pixels per workgroup
     static constexpr int kChunks = 4 * C / 32;               // hidden chunks of 32
-    static constexpr int kChunkBytes = 256 * C;              // [32][C] + [C][32] fp32
-    static constexpr int kPieces = kChunkBytes / 1024 / kWaves;   // 1-KB DMA pieces per wave per chunk (6)
-    static constexpr int kW1Chunks16 = 8 * C;                // 16-B chunks in the W1c part
+    static constexpr int kHalfBytes = 128 * C;               // one [32][C] (or [C][32]) fp32 image
+    static constexpr int kPieces = kHalfBytes / 1024 / kWaves;    // 1-KB DMA pieces per wave per image (3 / 6)
     static constexpr int kRowChunks = C / 4;                 // 16-B chunks per W1c row
-    static constexpr size_t kLdsBytes = 2 * (size_t)kChunkBytes + 4 * C * 4;   // + bias1
+    static constexpr size_t kLdsBytes = 4 * (size_t)kHalfBytes + 4 * C * 4;   // W1 ring[2] + W2 ring[2] + bias1
     __device__ static int swz1(int row) { return (C == 96) ? ((row >> 1) & 7) : (row & 15); }
 };
 
+// Software pipeline over hidden chunks j (32 hidden units each), per wave:
+//   stage A:  X(j+1) = bias + W1c(j+1) . act^T     C/2 chained MFMAs      } independent streams, issued
+//             G(j)   = gelu(X(j))                   16 x 14 VALU           } interleaved (VALU under MFMA)
+//   stage B:  out   += W2c(j) . G(j)                C/2 MFMAs
+// W1c and W2c live in two 2-deep LDS rings filled by LDS-DMA: iteration j issues W1c(j+2) and W2c(j+1).
 template <int C>
 __global__ __launch_bounds__(FusedCfg<C>::kThreads) void mlp_fused_kernel(
     const float* __restrict__ y, float* __restrict__ x, const float* __restrict__ wpack /*[chunks][64*C]*/,
     const float* __restrict__ b1, const float* __restrict__ b2, long long M) {
     using Cfg = FusedCfg<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* wbuf = smem;                                                   // [2][kChunkBytes]
-    float* b1s = reinterpret_cast<float*>(smem + 2 * Cfg::kChunkBytes);  // [4C]
+    char* w1buf = smem;                                                  // [2][kHalfBytes]  rows = hidden
+    char* w2buf = smem + 2 * Cfg::kHalfBytes;                            // [2][kHalfBytes]  rows = out channel
+    float* b1s = reinterpret_cast<float*>(smem + 4 * Cfg::kHalfBytes);   // [4C]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -69,32 +74,27 @@ __global__ __launch_bounds__(FusedCfg<C>::kThreads) void mlp_fused_kernel(
     const bool valid = mrow < M;
     if (!valid) mrow = M - 1;
 
-    // ---- LDS-DMA source offsets (in floats, relative to the chunk block) for this lane's pieces --------
-    int dma_src[Cfg::kPieces];
+    // ---- LDS-DMA source offsets (floats, relative to the chunk block [W1c | W2c]) for this lane ----------
+    int src1[Cfg::kPieces], src2[Cfg::kPieces];
 #pragma unroll
     for (int k = 0; k < Cfg::kPieces; ++k) {
         const int idx = (wave * Cfg::kPieces + k) * 64 + lane;           // linear 16-B slot in the LDS image
-        int src;
-        if (idx < Cfg::kW1Chunks16) {
-            const int row = idx / Cfg::kRowChunks, pos = idx - row * Cfg::kRowChunks;
-            src = row * Cfg::kRowChunks + (pos ^ Cfg::swz1(row));
-        } else {
-            const int i2 = idx - Cfg::kW1Chunks16;
-            const int row = i2 >> 3, pos = i2 & 7;
-            src = Cfg::kW1Chunks16 + row * 8 + (pos ^ ((row >> 1) & 7));
-        }
-        dma_src[k] = src * 4;
+        const int r1 = idx / Cfg::kRowChunks, p1 = idx - r1 * Cfg::kRowChunks;
+        src1[k] = (r1 * Cfg::kRowChunks + (p1 ^ Cfg::swz1(r1))) * 4;
+        const int r2 = idx >> 3, p2 = idx & 7;
+        src2[k] = 32 * C + (r2 * 8 + (p2 ^ ((r2 >> 1) & 7))) * 4;
     }
-#define ACX_DMA_CHUNK(j, buf)                                                                                   \
+#define ACX_DMA(srcv, j, dstbase)                                                                               \
     {                                                                                                           \
         const float* cb = wpack + (long long)(j) * (64 * C);                                                    \
         _Pragma("unroll") for (int k = 0; k < Cfg::kPieces; ++k)                                                \
             __builtin_amdgcn_global_load_lds(                                                                   \
-                (const __attribute__((address_space(1))) void*)(cb + dma_src[k]),                               \
-                (__attribute__((address_space(3))) void*)(wbuf + (buf) * Cfg::kChunkBytes +                     \
-                                                          (wave * Cfg::kPieces + k) * 1024), 16, 0, 0);         \
+                (const __attribute__((address_space(1))) void*)(cb + srcv[k]),                                  \
+                (__attribute__((address_space(3))) void*)((dstbase) + (wave * Cfg::kPieces + k) * 1024), 16, 0, 0); \
     }
-    ACX_DMA_CHUNK(0, 0);
+    ACX_DMA(src1, 0, w1buf);
+    ACX_DMA(src2, 0, w2buf);
+    ACX_DMA(src1, 1, w1buf + Cfg::kHalfBytes);
     for (int i = tid; i < 4 * C; i += Cfg::kThreads) b1s[i] = b1[i];
 
     // ---- this wave's activations: lane (px = l31, half hh) holds channels [hh*C/2, hh*C/2 + C/2) ------
@@ -126,46 +126,75 @@ __global__ __launch_bounds__(FusedCfg<C>::kThreads) void mlp_fused_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // fragment read offsets (bytes) in the chunk image
+    // fragment read offsets (bytes)
     const int sw1 = Cfg::swz1(l31);
     const int w1row = l31 * (4 * C);
     const int sw2 = (l31 >> 1) & 7;
-    const int w2base = Cfg::kW1Chunks16 * 16 + l31 * 128;
-    __syncthreads();      // chunk 0 landed (hipcc drains the LDS-DMA in front of the barrier), b1s visible
+    const int w2row = l31 * 128;
+
+#define ACX_PHASE1(Xv, j, w1p)                                                                                  \
+    {                                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j) + 8 * q + 4 * hh);                  \
+            Xv[4 * q + 0] = bq[0]; Xv[4 * q + 1] = bq[1]; Xv[4 * q + 2] = bq[2]; Xv[4 * q + 3] = bq[3];         \
+        }                                                                                                       \
+        _Pragma("unroll") for (int t = 0; t < C / 8; ++t) {                                                     \
+            const f32x4 a = *reinterpret_cast<const f32x4*>((w1p) + w1row + (((hh * (C / 8) + t) ^ sw1) << 4)); \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                       \
+                Xv = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], act[4 * t + e], Xv, 0, 0, 0);                   \
+        }                                                                                                       \
+    }
+    __syncthreads();      // W1c(0), W1c(1), W2c(0) landed (hipcc drains the LDS-DMA before the barrier); b1s visible
+    f32x16 X;
+    ACX_PHASE1(X, 0, w1buf)
+    __syncthreads();      // every wave is done with W1 ring slot 0 before iteration 0 refills it
 
     for (int j = 0; j < Cfg::kChunks; ++j) {
-        const char* wb = wbuf + (j & 1) * Cfg::kChunkBytes;
-        if (j + 1 < Cfg::kChunks) ACX_DMA_CHUNK(j + 1, (j + 1) & 1);
+        if (j + 2 < Cfg::kChunks) ACX_DMA(src1, j + 2, w1buf + (j & 1) * Cfg::kHalfBytes);
+        if (j + 1 < Cfg::kChunks) ACX_DMA(src2, j + 1, w2buf + ((j + 1) & 1) * Cfg::kHalfBytes);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 1: X^T = W1c . act^T, accumulator pre-loaded with the bias -------------------------
-        f32x16 X;
+        f32x16 Xn;
+        if (j + 1 < Cfg::kChunks) {
+            const char* w1p = w1buf + ((j + 1) & 1) * Cfg::kHalfBytes;
+            ACX_PHASE1(Xn, j + 1, w1p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * j + 8 * q + 4 * hh);
-            X[4 * q + 0] = bq[0]; X[4 * q + 1] = bq[1]; X[4 * q + 2] = bq[2]; X[4 * q + 3] = bq[3];
+            for (int r = 0; r < 16; ++r) X[r] = gelu_erf_f(X[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { X[r] = gelu_erf_f(X[r]); Xn[r] = 0.f; }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const char* w2p = w2buf + (j & 1) * Cfg::kHalfBytes + w2row;
+        // W2c fragments double-buffered in two NAMED registers with sched_barriers between the read of
+        // group i+1 and the 4 MFMAs of group i: hipcc otherwise reuses one register quad and waits on every
+        // ds_read right in front of its (dependent-chain) MFMAs -- an LDS round trip per 4 MFMAs.
+#define ACX_W2_READ(i_) (*reinterpret_cast<const f32x4*>(w2p + ((i_) >> 2) * 4096 + (((2 * ((i_) & 3) + hh) ^ sw2) << 4)))
+#define ACX_W2_MFMA(i_, a_)                                                                                    \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                           \
+            acc[(i_) >> 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[e], X[4 * ((i_) & 3) + e], acc[(i_) >> 2], 0, 0, 0);
+        f32x4 a0 = ACX_W2_READ(0), a1;
 #pragma unroll
-        for (int t = 0; t < C / 8; ++t) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(wb + w1row + (((hh * (C / 8) + t) ^ sw1) << 4));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) X = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], act[4 * t + e], X, 0, 0, 0);
+        for (int i = 0; i < C / 8; i += 2) {
+            a1 = ACX_W2_READ(i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            ACX_W2_MFMA(i, a0)
+            __builtin_amdgcn_sched_barrier(0);
+            // With an LDS-DMA in flight hipcc only emits lgkmcnt(0): consume a1 HERE (its read is 4 MFMAs old)
+            // so that the wait does not also cover the read issued next.
+            asm volatile("" :: "v"(a1));
+            if (i + 2 < C / 8) a0 = ACX_W2_READ(i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            ACX_W2_MFMA(i + 1, a1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 2 < C / 8) asm volatile("" :: "v"(a0));
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) X[r] = gelu_erf_f(X[r]);
-        // ---- phase 2: out^T += W2c . X^T --------------------------------------------------------------
-#pragma unroll
-        for (int t = 0; t < C / 32; ++t) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(wb + w2base + t * 4096 + (((2 * q + hh) ^ sw2) << 4));
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], X[4 * q + e], acc[t], 0, 0, 0);
-            }
-        }
+#undef ACX_W2_READ
+#undef ACX_W2_MFMA
+        X = Xn;
         __syncthreads();
     }
-#undef ACX_DMA_CHUNK
+#undef ACX_DMA
+#undef ACX_PHASE1
 
     // ---- epilogue: lane (px, hh), tile t, q: channels 32t + 8q + 4hh .. +3  ->  x = x + out + b2 ---------
     if (valid) {
