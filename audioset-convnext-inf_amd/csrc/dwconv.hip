@@ -14,86 +14,158 @@ namespace acx {
 
 constexpr int kDwSlice = 32;      // channels per workgroup (8 lanes x float4)
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Streaming form: a workgroup owns (clip, 32-channel slice, column strip of TW pixels, segment of row tiles)
+// and walks DOWN the image.  An LDS ring of TH+6 input rows is kept; each step computes TH output rows from
+// the ring while the next TH input rows are already in flight to registers (issued before the FMAs, written
+// into the ring slots of the TH oldest rows after them), so every input row is fetched once per strip
+// (the first tile-only version re-read its 6 halo rows per tile: FETCH_SIZE 1.93x the algorithmic bytes,
+// profiles/r01_c_pmc_per_kernel.csv) and HBM latency hides under the arithmetic.
 template <int TW, int TH>
 struct DwCfg {
     static constexpr int WT = 7;
     static constexpr int kStrips = TW / WT;
     static constexpr int kThreads = kStrips * 8 * TH;
     static constexpr int kCols = TW + 6;
-    static constexpr int kRows = TH + 6;
-    static constexpr int kTileF4 = kRows * kCols * 8;
-    static constexpr size_t kLdsBytes = (size_t)(kTileF4 + 49 * 8) * 16;
+    static constexpr int kRing = TH + 6;
+    static constexpr int kRowF4 = kCols * 8;                      // float4 per ring row
+    static constexpr int kStepF4 = TH * kRowF4;                   // float4 fetched per step
+    static constexpr int kStage = (kStepF4 + kThreads - 1) / kThreads;   // staging float4 per thread
+    static constexpr size_t kLdsBytes = (size_t)(kRing * kRowF4 + 49 * 8) * 16;
 };
 
 template <int TW, int TH>
-__global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                       const float* __restrict__ wt /*[49][C]*/,
                                                       const float* __restrict__ bias, int H, int W, int C,
-                                                      int tiles_w, int tiles_h) {
+                                                      int tiles_w, int tiles_h, int n_seg) {
     using Cfg = DwCfg<TW, TH>;
+    static_assert(Cfg::kThreads == 256, "thread mapping assumes 256 threads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* tile = reinterpret_cast<float4*>(smem);                 // [kRows][kCols][8]
-    float4* wl = tile + Cfg::kTileF4;                               // [49][8]
+    f32x4* ring = reinterpret_cast<f32x4*>(smem);                  // [kRing][kCols][8]
+    f32x4* wl = ring + Cfg::kRing * Cfg::kRowF4;                   // [49][8]
 
     int bid = blockIdx.x;
     const int slice = bid % (C / kDwSlice); bid /= (C / kDwSlice);
     const int tw = bid % tiles_w; bid /= tiles_w;
-    const int th = bid % tiles_h; bid /= tiles_h;
+    const int seg = bid % n_seg; bid /= n_seg;
     const long long b = bid;
     const int c0 = slice * kDwSlice;
-    const int h0 = th * TH, w0 = tw * TW;
+    const int w0 = tw * TW;
     const int tid = threadIdx.x;
+    // balanced segments of row tiles
+    const int t_begin = (int)((long long)tiles_h * seg / n_seg);
+    const int t_end = (int)((long long)tiles_h * (seg + 1) / n_seg);
+    if (t_begin >= t_end) return;
 
     for (int i = tid; i < 49 * 8; i += Cfg::kThreads)
-        wl[i] = *reinterpret_cast<const float4*>(wt + (i >> 3) * C + c0 + 4 * (i & 7));
-    const float* xb = x + b * (long long)H * W * C;
-    for (int i = tid; i < Cfg::kTileF4; i += Cfg::kThreads) {
+        wl[i] = *reinterpret_cast<const f32x4*>(wt + (i >> 3) * C + c0 + 4 * (i & 7));
+    const float* xb = x + b * (long long)H * W * C + c0;
+
+    // staging coordinates of this thread's float4 #k within a step of TH rows: (row, col, quad)
+    int st_row[Cfg::kStage], st_off[Cfg::kStage];      // st_off: element offset of (col, quad) in an image row, or -1
+#pragma unroll
+    for (int k = 0; k < Cfg::kStage; ++k) {
+        const int i = tid + k * Cfg::kThreads;
         const int q = i & 7;
         const int col = (i >> 3) % Cfg::kCols;
-        const int row = (i >> 3) / Cfg::kCols;
-        const int gh = h0 - 3 + row, gw = w0 - 3 + col;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gh >= 0 && gh < H && gw >= 0 && gw < W)
-            v = *reinterpret_cast<const float4*>(xb + ((long long)gh * W + gw) * C + c0 + 4 * q);
-        tile[i] = v;
+        st_row[k] = (i >> 3) / Cfg::kCols;
+        const int gw = w0 - 3 + col;
+        st_off[k] = (i < Cfg::kStepF4 && gw >= 0 && gw < W) ? gw * C + 4 * q : -1;
+    }
+    // ring slot of input row g (g = image row + 3 - 8-row-aligned segment origin) is g mod kRing
+    const int g_origin = t_begin * TH - 3;             // image row stored as ring row 0 of this segment
+    f32x4 rg[Cfg::kStage];
+#define ACX_DW_LOAD(first_row, pred)  /* image rows first_row .. +TH-1 -> registers (zeros outside) */ \
+    _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {                                             \
+        const int gh = (first_row) + st_row[k];                                                           \
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                   \
+        if ((pred) && st_off[k] >= 0 && gh >= 0 && gh < H)                                                \
+            v = *reinterpret_cast<const f32x4*>(xb + (long long)gh * W * C + st_off[k]);                  \
+        rg[k] = v;                                                                                        \
+    }
+#define ACX_DW_STORE(first_row) /* registers -> ring rows of image rows first_row.. */                    \
+    _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {                                             \
+        const int i = tid + k * Cfg::kThreads;                                                            \
+        if (i < Cfg::kStepF4) {                                                                           \
+            const int slot = ((first_row) - g_origin + st_row[k]) % Cfg::kRing;                           \
+            ring[slot * Cfg::kRowF4 + (i - st_row[k] * Cfg::kRowF4)] = rg[k];                             \
+        }                                                                                                 \
+    }
+    // prologue: rows [g_origin, g_origin + TH + 6) in two rounds (the second may overshoot by TH-6 rows)
+    ACX_DW_LOAD(g_origin, true)
+    ACX_DW_STORE(g_origin)
+    {
+        // remaining 6 rows: reuse the step loader on rows g_origin+TH .. (only the first 6 are kept)
+        _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {
+            const int gh = g_origin + TH + st_row[k];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (st_row[k] < 6 && st_off[k] >= 0 && gh >= 0 && gh < H)
+                v = *reinterpret_cast<const f32x4*>(xb + (long long)gh * W * C + st_off[k]);
+            rg[k] = v;
+        }
+        _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {
+            const int i = tid + k * Cfg::kThreads;
+            if (i < Cfg::kStepF4 && st_row[k] < 6)
+                ring[(TH + st_row[k]) * Cfg::kRowF4 + (i - st_row[k] * Cfg::kRowF4)] = rg[k];
+        }
     }
     __syncthreads();
 
     const int q = tid & 7;
     const int strip = (tid >> 3) % Cfg::kStrips;
     const int r = (tid >> 3) / Cfg::kStrips;
-    const float4 bv = *reinterpret_cast<const float4*>(bias + c0 + 4 * q);
-    float4 acc[Cfg::WT];
-#pragma unroll
-    for (int i = 0; i < Cfg::WT; ++i) acc[i] = bv;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0 + 4 * q);
 
+    for (int t = t_begin; t < t_end; ++t) {
+        const int h0 = t * TH;
+        const bool more = t + 1 < t_end;
+        // next step's rows: image rows h0 + TH + 3 .. h0 + 2TH + 2  (ring rows of the TH oldest)
+        const int next_first = h0 + TH + 3;
+        ACX_DW_LOAD(next_first, more)
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x4 acc[Cfg::WT];
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky) {
-        float4 wk[7];
+        for (int i = 0; i < Cfg::WT; ++i) acc[i] = bv;
+        int qw = q;                       // opaque per tile: keeps hipcc from hoisting all 49 weight float4
+        asm volatile("" : "+v"(qw));      // (196 VGPRs) out of the tile loop -- they are re-read from LDS instead
+        const int base = (h0 - 3 - g_origin + r) % Cfg::kRing;    // ring slot of input row h0 - 3 + r
+#pragma unroll 1
+        for (int ky = 0; ky < 7; ++ky) {
+            f32x4 wk[7];
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx) wk[kx] = wl[(ky * 7 + kx) * 8 + q];
-        const float4* rowp = tile + ((r + ky) * Cfg::kCols + strip * Cfg::WT) * 8 + q;
+            for (int kx = 0; kx < 7; ++kx) wk[kx] = wl[(ky * 7 + kx) * 8 + qw];
+            int slot = base + ky;
+            if (slot >= Cfg::kRing) slot -= Cfg::kRing;
+            const f32x4* rowp = ring + (slot * Cfg::kCols + strip * Cfg::WT) * 8 + q;
 #pragma unroll
-        for (int j = 0; j < Cfg::WT + 6; ++j) {
-            const float4 in = rowp[j * 8];
+            for (int j = 0; j < Cfg::WT + 6; ++j) {
+                const f32x4 in = rowp[j * 8];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                const int i = j - kx;
-                if (i >= 0 && i < Cfg::WT) {
-                    acc[i].x = fmaf(in.x, wk[kx].x, acc[i].x);
-                    acc[i].y = fmaf(in.y, wk[kx].y, acc[i].y);
-                    acc[i].z = fmaf(in.z, wk[kx].z, acc[i].z);
-                    acc[i].w = fmaf(in.w, wk[kx].w, acc[i].w);
+                for (int kx = 0; kx < 7; ++kx) {
+                    const int i = j - kx;
+                    if (i >= 0 && i < Cfg::WT) acc[i] += in * wk[kx];
                 }
             }
         }
-    }
-    const int h = h0 + r;
-    if (h < H) {
-        float* yp = y + ((b * H + h) * (long long)W + w0 + strip * Cfg::WT) * C + c0 + 4 * q;
+        const int h = h0 + r;
+        if (h < H) {
+            float* yp = y + ((b * H + h) * (long long)W + w0 + strip * Cfg::WT) * C + c0 + 4 * q;
 #pragma unroll
-        for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<float4*>(yp + (long long)i * C) = acc[i];
+            for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x4*>(yp + (long long)i * C) = acc[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            __syncthreads();                                       // everyone is done reading the ring
+            asm volatile("" : "+v"(rg[0]));                        // keep the vmcnt wait down here
+            ACX_DW_STORE(next_first)
+            __syncthreads();
+        }
     }
+#undef ACX_DW_LOAD
+#undef ACX_DW_STORE
 }
 
 // Per-row LayerNorm statistics over C channels (biased variance, eps inside the sqrt --
@@ -182,9 +254,14 @@ static int launch_dw_cfg(const BlockW& w, int C, const float* x, float* y, int B
         attr_set = true;
     }
     const int tiles_w = W / TW, tiles_h = (H + TH - 1) / TH;
-    const long long blocks = (long long)B * tiles_h * tiles_w * (C / kDwSlice);
+    const long long columns = (long long)B * tiles_w * (C / kDwSlice);
+    // enough workgroups for ~4 rounds on 256 CUs x 2 resident, but segments of at least 2 row tiles
+    int n_seg = (int)((2048 + columns - 1) / columns);
+    if (n_seg > tiles_h / 2) n_seg = tiles_h / 2;
+    if (n_seg < 1) n_seg = 1;
+    const long long blocks = columns * n_seg;
     dwconv7_kernel<TW, TH><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(
-        x, y, w.dw, w.dwb, H, W, C, tiles_w, tiles_h);
+        x, y, w.dw, w.dwb, H, W, C, tiles_w, tiles_h, n_seg);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
@@ -198,7 +275,7 @@ int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const float* x, float* y, 
             case 56: rc = launch_dw_cfg<28, 8>(w, C, x, y, B, H, W, s); break;
             case 28: rc = launch_dw_cfg<28, 8>(w, C, x, y, B, H, W, s); break;
             case 14: rc = launch_dw_cfg<14, 16>(w, C, x, y, B, H, W, s); break;
-            case 7: rc = launch_dw_cfg<7, 32>(w, C, x, y, B, H, W, s); break;
+            case 7: rc = launch_dw_cfg<7, 32>(w, C, x, y, B, H, W, s); break;   // 31x7 image: one step
             default: ACX_FAIL(ACX_ERR_SHAPE, "dwconv7: unsupported width %d (expected 56/28/14/7)", W);
         }
         ACX_TRY(rc);
