@@ -63,54 +63,47 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
         wl[i] = *reinterpret_cast<const f32x4*>(wt + (i >> 3) * C + c0 + 4 * (i & 7));
     const float* xb = x + b * (long long)H * W * C + c0;
 
-    // staging coordinates of this thread's float4 #k within a step of TH rows: (row, col, quad)
-    int st_row[Cfg::kStage], st_off[Cfg::kStage];      // st_off: element offset of (col, quad) in an image row, or -1
+    // staging coordinates of this thread's float4 #k within a step of TH rows: (row, col, quad).
+    // Loads are UNCONDITIONAL on clamped (always valid) addresses and zero-padding is applied when the
+    // registers are written to the ring: a per-element "load or zero" makes hipcc branch around every load
+    // and wait for all of them right there, which would serialise the prefetch with the FMAs.
+    int st_row[Cfg::kStage], st_off[Cfg::kStage];
+    unsigned col_ok = 0;                                // bit k: column inside the image and slot in range
 #pragma unroll
     for (int k = 0; k < Cfg::kStage; ++k) {
         const int i = tid + k * Cfg::kThreads;
-        const int q = i & 7;
+        const int qq = i & 7;
         const int col = (i >> 3) % Cfg::kCols;
-        st_row[k] = (i >> 3) / Cfg::kCols;
+        st_row[k] = (i < Cfg::kStepF4) ? (i >> 3) / Cfg::kCols : 0;
         const int gw = w0 - 3 + col;
-        st_off[k] = (i < Cfg::kStepF4 && gw >= 0 && gw < W) ? gw * C + 4 * q : -1;
+        const int gwc = gw < 0 ? 0 : (gw >= W ? W - 1 : gw);
+        st_off[k] = gwc * C + 4 * qq;
+        if (i < Cfg::kStepF4 && gw >= 0 && gw < W) col_ok |= 1u << k;
     }
-    // ring slot of input row g (g = image row + 3 - 8-row-aligned segment origin) is g mod kRing
-    const int g_origin = t_begin * TH - 3;             // image row stored as ring row 0 of this segment
+    const int g_origin = t_begin * TH - 3;             // image row kept in ring row 0 of this segment
     f32x4 rg[Cfg::kStage];
-#define ACX_DW_LOAD(first_row, pred)  /* image rows first_row .. +TH-1 -> registers (zeros outside) */ \
+#define ACX_DW_LOAD(first_row)  /* image rows first_row .. +TH-1 -> registers (row index clamped) */      \
     _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {                                             \
-        const int gh = (first_row) + st_row[k];                                                           \
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                   \
-        if ((pred) && st_off[k] >= 0 && gh >= 0 && gh < H)                                                \
-            v = *reinterpret_cast<const f32x4*>(xb + (long long)gh * W * C + st_off[k]);                  \
-        rg[k] = v;                                                                                        \
+        int gh = (first_row) + st_row[k];                                                                 \
+        gh = gh < 0 ? 0 : (gh >= H ? H - 1 : gh);                                                         \
+        rg[k] = *reinterpret_cast<const f32x4*>(xb + (long long)gh * W * C + st_off[k]);                  \
     }
-#define ACX_DW_STORE(first_row) /* registers -> ring rows of image rows first_row.. */                    \
+#define ACX_DW_STORE(first_row, max_rows) /* registers -> ring rows, zero outside the image */            \
     _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {                                             \
         const int i = tid + k * Cfg::kThreads;                                                            \
-        if (i < Cfg::kStepF4) {                                                                           \
-            const int slot = ((first_row) - g_origin + st_row[k]) % Cfg::kRing;                           \
-            ring[slot * Cfg::kRowF4 + (i - st_row[k] * Cfg::kRowF4)] = rg[k];                             \
+        if (i < Cfg::kStepF4 && st_row[k] < (max_rows)) {                                                 \
+            const int gh = (first_row) + st_row[k];                                                       \
+            const bool ok = ((col_ok >> k) & 1u) && gh >= 0 && gh < H;                                    \
+            const int slot = (gh - g_origin) % Cfg::kRing;                                                \
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};                                                         \
+            ring[slot * Cfg::kRowF4 + (i - st_row[k] * Cfg::kRowF4)] = ok ? rg[k] : z;                    \
         }                                                                                                 \
     }
-    // prologue: rows [g_origin, g_origin + TH + 6) in two rounds (the second may overshoot by TH-6 rows)
-    ACX_DW_LOAD(g_origin, true)
-    ACX_DW_STORE(g_origin)
-    {
-        // remaining 6 rows: reuse the step loader on rows g_origin+TH .. (only the first 6 are kept)
-        _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {
-            const int gh = g_origin + TH + st_row[k];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (st_row[k] < 6 && st_off[k] >= 0 && gh >= 0 && gh < H)
-                v = *reinterpret_cast<const f32x4*>(xb + (long long)gh * W * C + st_off[k]);
-            rg[k] = v;
-        }
-        _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {
-            const int i = tid + k * Cfg::kThreads;
-            if (i < Cfg::kStepF4 && st_row[k] < 6)
-                ring[(TH + st_row[k]) * Cfg::kRowF4 + (i - st_row[k] * Cfg::kRowF4)] = rg[k];
-        }
-    }
+    // prologue: image rows [g_origin, g_origin + TH + 6) in two rounds (of the second only 6 rows are kept)
+    ACX_DW_LOAD(g_origin)
+    ACX_DW_STORE(g_origin, TH)
+    ACX_DW_LOAD(g_origin + TH)
+    ACX_DW_STORE(g_origin + TH, 6)
     __syncthreads();
 
     const int q = tid & 7;
@@ -123,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
         const bool more = t + 1 < t_end;
         // next step's rows: image rows h0 + TH + 3 .. h0 + 2TH + 2  (ring rows of the TH oldest)
         const int next_first = h0 + TH + 3;
-        ACX_DW_LOAD(next_first, more)
+        ACX_DW_LOAD(next_first)           // (on the last tile of the segment: a discarded, in-range load)
         __builtin_amdgcn_sched_barrier(0);
 
         f32x4 acc[Cfg::WT];
@@ -132,24 +125,63 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
         int qw = q;                       // opaque per tile: keeps hipcc from hoisting all 49 weight float4
         asm volatile("" : "+v"(qw));      // (196 VGPRs) out of the tile loop -- they are re-read from LDS instead
         const int base = (h0 - 3 - g_origin + r) % Cfg::kRing;    // ring slot of input row h0 - 3 + r
-#pragma unroll 1
-        for (int ky = 0; ky < 7; ++ky) {
-            f32x4 wk[7];
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx) wk[kx] = wl[(ky * 7 + kx) * 8 + qw];
-            int slot = base + ky;
-            if (slot >= Cfg::kRing) slot -= Cfg::kRing;
-            const f32x4* rowp = ring + (slot * Cfg::kCols + strip * Cfg::WT) * 8 + q;
-#pragma unroll
-            for (int j = 0; j < Cfg::WT + 6; ++j) {
-                const f32x4 in = rowp[j * 8];
-#pragma unroll
-                for (int kx = 0; kx < 7; ++kx) {
-                    const int i = j - kx;
-                    if (i >= 0 && i < Cfg::WT) acc[i] += in * wk[kx];
-                }
-            }
+        // The 7 kernel rows are software-pipelined by hand in HALF rows: the LDS reads of the next unit
+        // (7 or 6 input float4, and once per row the 7 weight float4 of the next kernel row) are issued into
+        // a second register set BEFORE the 49 packed FMAs of the current unit.  With two waves per SIMD there
+        // is not enough TLP to cover an LDS round trip per kernel row otherwise (the rolled loop spent 55 % of
+        // its wave time in s_waitcnt).  Half rows keep the double buffers at 112 VGPRs.
+        f32x4 iA[7], iB[6], wA[7], wB[7];
+#define ACX_DW_ROWP(ky_, p_)                                                                              \
+        const f32x4* p_;                                                                                  \
+        {                                                                                                 \
+            int slot = base + (ky_);                                                                      \
+            if (slot >= Cfg::kRing) slot -= Cfg::kRing;                                                   \
+            p_ = ring + (slot * Cfg::kCols + strip * Cfg::WT) * 8 + q;                                    \
         }
+#define ACX_DW_READ_W(w_, ky_) _Pragma("unroll") for (int kx = 0; kx < 7; ++kx) w_[kx] = wl[((ky_) * 7 + kx) * 8 + qw];
+#define ACX_DW_READ_I0(ky_) { ACX_DW_ROWP(ky_, p0_) _Pragma("unroll") for (int j = 0; j < 7; ++j) iA[j] = p0_[j * 8]; }
+#define ACX_DW_READ_I1(ky_) { ACX_DW_ROWP(ky_, p1_) _Pragma("unroll") for (int j = 0; j < 6; ++j) iB[j] = p1_[(7 + j) * 8]; }
+#define ACX_DW_PIN _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) asm volatile("" : "+v"(acc[i]));
+        // opaque re-definition of acc pins the FMAs in place (plain arithmetic is otherwise sunk below later reads)
+#define ACX_DW_FMA0(w_)                                                                                   \
+        {                                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 7; ++j)                                                 \
+            _Pragma("unroll") for (int kx = 0; kx <= j; ++kx) acc[j - kx] += iA[j] * w_[kx];              \
+            ACX_DW_PIN                                                                                    \
+        }
+#define ACX_DW_FMA1(w_)                                                                                   \
+        {                                                                                                 \
+            _Pragma("unroll") for (int j = 7; j < 13; ++j)                                                \
+            _Pragma("unroll") for (int kx = j - 6; kx < 7; ++kx) acc[j - kx] += iB[j - 7] * w_[kx];       \
+            ACX_DW_PIN                                                                                    \
+        }
+#define ACX_DW_TOUCH(arr_, n_) _Pragma("unroll") for (int z = 0; z < (n_); ++z) asm volatile("" :: "v"(arr_[z]));
+#define ACX_DW_KROW(ky_, wc_, wn_)   /* kernel row ky_ with weights wc_; prefetches row ky_+1 into wn_ */   \
+        {                                                                                                 \
+            ACX_DW_READ_I1(ky_)                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            ACX_DW_FMA0(wc_)                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            ACX_DW_TOUCH(iB, 6)                                                                           \
+            if ((ky_) + 1 < 7) { ACX_DW_READ_W(wn_, (ky_) + 1) ACX_DW_READ_I0((ky_) + 1) }                \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            ACX_DW_FMA1(wc_)                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            if ((ky_) + 1 < 7) { ACX_DW_TOUCH(wn_, 7) ACX_DW_TOUCH(iA, 7) }                               \
+        }
+        ACX_DW_READ_W(wA, 0)
+        ACX_DW_READ_I0(0)
+        ACX_DW_KROW(0, wA, wB) ACX_DW_KROW(1, wB, wA) ACX_DW_KROW(2, wA, wB) ACX_DW_KROW(3, wB, wA)
+        ACX_DW_KROW(4, wA, wB) ACX_DW_KROW(5, wB, wA) ACX_DW_KROW(6, wA, wB)
+#undef ACX_DW_ROWP
+#undef ACX_DW_READ_W
+#undef ACX_DW_READ_I0
+#undef ACX_DW_READ_I1
+#undef ACX_DW_PIN
+#undef ACX_DW_FMA0
+#undef ACX_DW_FMA1
+#undef ACX_DW_TOUCH
+#undef ACX_DW_KROW
         const int h = h0 + r;
         if (h < H) {
             float* yp = y + ((b * H + h) * (long long)W + w0 + strip * Cfg::WT) * C + c0 + 4 * q;
@@ -160,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
         if (more) {
             __syncthreads();                                       // everyone is done reading the ring
             asm volatile("" : "+v"(rg[0]));                        // keep the vmcnt wait down here
-            ACX_DW_STORE(next_first)
+            ACX_DW_STORE(next_first, TH)
             __syncthreads();
         }
     }
