@@ -24,7 +24,6 @@ namespace acx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBM = 128;
 constexpr int kBK = 32;
 constexpr int kRowBytes = kBK * 4;        // 128-B LDS rows
 
@@ -61,7 +60,7 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, char* lds_wave_base
 }
 
 // GATHER: 0 plain rows, 1 2x2 patch gather (downsample)
-template <int BN, int WM, int WN, int EPI, int GATHER>
+template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int TM = kBM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
@@ -76,8 +75,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile_n = blockIdx.x % p.tiles_n;
-    const long long tile_m = blockIdx.x / p.tiles_n;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so
+    // logical tile id L = (bid % 8) * ceil(n/8) + bid / 8 gives every XCD a CONTIGUOUS run of tiles; with the
+    // n-tile index fastest, the tiles that share an A row-panel then sit on one XCD and hit its L2 instead of
+    // re-fetching the panel once per XCD (speed only: any placement is correct).
+    long long lid = blockIdx.x;
+    {
+        const long long nwg = gridDim.x, per = (nwg + 7) >> 3, full = nwg - (per - 1) * 8;   // XCDs 0..full-1 hold `per`
+        const long long xcd = lid & 7, k = lid >> 3;
+        lid = (xcd < full ? xcd * per : full * per + (xcd - full) * (per - 1)) + k;
+    }
+    const int tile_n = (int)(lid % p.tiles_n);
+    const long long tile_m = lid / p.tiles_n;
     const long long m0 = tile_m * kBM;
     const int n0 = tile_n * BN;
 
@@ -283,10 +292,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
-template <int BN>
-constexpr size_t gemm_lds_bytes() { return (size_t)2 * (kBM + BN) * kRowBytes; }
+template <int BM, int BN>
+constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * kRowBytes; }
 
-template <int BN, int WM, int WN, int EPI, int GATHER>
+template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
 static int launch_cfg(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_n = p.N / BN;
@@ -295,19 +304,26 @@ static int launch_cfg(const GemmParams& p0, hipStream_t s) {
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm: grid too large");
     static bool attr_set = false;
     if (!attr_set) {
-        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BN, WM, WN, EPI, GATHER>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<BN>()));
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<kBM, BN>()));
         attr_set = true;
     }
-    gemm_f32_kernel<BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(256), gemm_lds_bytes<BN>(), s>>>(p);
+    gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(256), gemm_lds_bytes<kBM, BN>(), s>>>(p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
 
 template <int EPI, int GATHER>
 static int launch_bn(const GemmParams& p, hipStream_t s) {
-    if (p.N % 128 == 0) return launch_cfg<128, 2, 2, EPI, GATHER>(p, s);
-    if (p.N % 96 == 0) return launch_cfg<96, 4, 1, EPI, GATHER>(p, s);
+    // 128-row tiles by default; 64-row tiles when the 128-row grid would not fill ~1.5 rounds of the
+    // 512 resident workgroups (stage-3 pwconv2, the last downsample): halves the tail-round loss.
+    const long long tiles128 = ((p.M + 127) / 128) * (p.N % 128 == 0 ? p.N / 128 : p.N / 96);
+    const bool small = tiles128 < 800;
+    if (p.N % 128 == 0) {
+        if (small) return launch_cfg<64, 128, 2, 2, EPI, GATHER>(p, s);
+        return launch_cfg<128, 128, 2, 2, EPI, GATHER>(p, s);
+    }
+    if (p.N % 96 == 0) return launch_cfg<128, 96, 4, 1, EPI, GATHER>(p, s);
     ACX_FAIL(ACX_ERR_SHAPE, "gemm: N=%d is not a multiple of 96 or 128", p.N);
 }
 
