@@ -18,54 +18,70 @@ __device__ __forceinline__ float block_sum256(float v, float* red /*[4]*/) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// One workgroup per clip.  x NHWC (B,H3,7,768):
+// One workgroup of 768 threads per clip.  x NHWC (B,H3,7,768):
 //   mean over the 7 frequency columns (torch.mean(x, dim=3)), then max over time + mean over time,
 //   nn.LayerNorm(768, eps=1e-6) -> scene embedding; Linear 768->527 -> logits; sigmoid -> probs.
-__global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ x, int H3,
+// Thread = (float4 of channels, one of 4 time phases): every thread streams ~H3/4 rows x 7 columns of
+// independent 16-B loads (the first version walked all H3 rows serially per thread: latency-bound, 143 us),
+// partial (max, sum) meet in LDS.
+__global__ __launch_bounds__(768) void pool_head_kernel(const float* __restrict__ x, int H3,
                                                         const float* __restrict__ nw, const float* __restrict__ nb,
                                                         const float* __restrict__ hw, const float* __restrict__ hb,
                                                         float* __restrict__ scene, float* __restrict__ logits,
                                                         float* __restrict__ probs) {
-    __shared__ float emb[768];
-    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float pmax[4][768];
+    __shared__ __attribute__((aligned(16))) float psum[4][768];
+    __shared__ __attribute__((aligned(16))) float emb[768];
+    __shared__ float red[12];
     const int tid = threadIdx.x;
+    const int cg = tid % 192, ph = tid / 192;
     const long long b = blockIdx.x;
-    const float* xb = x + b * (long long)H3 * 7 * 768;
-    float pooled[3];
+    const float* xb = x + b * (long long)H3 * 7 * 768 + 4 * cg;
+    float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), sm = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = ph; h < H3; h += 4) {
+        const float* r = xb + (long long)h * 7 * 768;
+        float4 v[7];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int c = tid + 256 * k;
-        float mx = -INFINITY, sm = 0.f;
-        for (int h = 0; h < H3; ++h) {
-            const float* r = xb + (long long)h * 7 * 768 + c;
-            float s = 0.f;
+        for (int w = 0; w < 7; ++w) v[w] = *reinterpret_cast<const float4*>(r + w * 768);
+        float4 s = v[0];
 #pragma unroll
-            for (int w = 0; w < 7; ++w) s += r[w * 768];
-            s *= (1.0f / 7.0f);
-            mx = fmaxf(mx, s);
-            sm += s;
-        }
-        pooled[k] = mx + sm / (float)H3;
+        for (int w = 1; w < 7; ++w) { s.x += v[w].x; s.y += v[w].y; s.z += v[w].z; s.w += v[w].w; }
+        s.x *= (1.0f / 7.0f); s.y *= (1.0f / 7.0f); s.z *= (1.0f / 7.0f); s.w *= (1.0f / 7.0f);
+        mx.x = fmaxf(mx.x, s.x); mx.y = fmaxf(mx.y, s.y); mx.z = fmaxf(mx.z, s.z); mx.w = fmaxf(mx.w, s.w);
+        sm.x += s.x; sm.y += s.y; sm.z += s.z; sm.w += s.w;
     }
-    const float mean = block_sum256(pooled[0] + pooled[1] + pooled[2], red) * (1.0f / 768.0f);
-    const float d0 = pooled[0] - mean, d1 = pooled[1] - mean, d2 = pooled[2] - mean;
-    const float var = block_sum256(d0 * d0 + d1 * d1 + d2 * d2, red) * (1.0f / 768.0f);
+    *reinterpret_cast<float4*>(&pmax[ph][4 * cg]) = mx;
+    *reinterpret_cast<float4*>(&psum[ph][4 * cg]) = sm;
+    __syncthreads();
+    // thread c: combine the 4 phases (time order of the sum is (h%4, h/4) -- fp32 re-association only)
+    const int c = tid;
+    const float m = fmaxf(fmaxf(pmax[0][c], pmax[1][c]), fmaxf(pmax[2][c], pmax[3][c]));
+    const float su = (psum[0][c] + psum[1][c]) + (psum[2][c] + psum[3][c]);
+    const float pooled = m + su / (float)H3;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) t += red[i];
+        return t;
+    };
+    const float mean = block_sum(pooled) * (1.0f / 768.0f);
+    const float d = pooled - mean;
+    const float var = block_sum(d * d) * (1.0f / 768.0f);
     const float rstd = 1.0f / sqrtf(var + 1e-6f);
-    const float d[3] = {d0, d1, d2};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int c = tid + 256 * k;
-        const float e = fmaf(d[k] * rstd, nw[c], nb[c]);
-        emb[c] = e;
-        if (scene) scene[b * 768 + c] = e;
-    }
+    const float e0 = fmaf(d * rstd, nw[c], nb[c]);
+    emb[c] = e0;
+    if (scene) scene[b * 768 + c] = e0;
     __syncthreads();
     if (!logits && !probs) return;
     const int lane = tid & 63, wave = tid >> 6;
     float4 e[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) e[k] = *reinterpret_cast<const float4*>(&emb[4 * (lane + 64 * k)]);
-    for (int n = wave; n < kClasses; n += 4) {
+    for (int n = wave; n < kClasses; n += 12) {
         const float4* wr = reinterpret_cast<const float4*>(hw + (long long)n * 768);
         float s = 0.f;
 #pragma unroll
@@ -86,7 +102,7 @@ __global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict_
 int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
                      hipStream_t s) {
     ProfScope ps(c, ACX_K_POOLHEAD, s);
-    pool_head_kernel<<<dim3(B), dim3(256), 0, s>>>(x, H3, c->d_norm_w, c->d_norm_b, c->d_head_w, c->d_head_b,
+    pool_head_kernel<<<dim3(B), dim3(768), 0, s>>>(x, H3, c->d_norm_w, c->d_norm_b, c->d_head_w, c->d_head_b,
                                                    scene, logits, probs);
     ACX_HIP(hipGetLastError());
     return ACX_OK;

@@ -20,12 +20,15 @@ __device__ __forceinline__ float half_sum32(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, int T, int H0, long long npix,
+constexpr int kStemPix = 4;     // consecutive output pixels (same row) per 32-lane group per iteration: 16
+                                // independent 16-B loads in flight per lane instead of 4
+
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, int T, int H0, long long ngroups,
                                                    const float* __restrict__ w /*[96][16]*/,
                                                    const float* __restrict__ bias, const float* __restrict__ lnw,
                                                    const float* __restrict__ lnb, float* __restrict__ out) {
     const int l32 = threadIdx.x & 31;
-    const int sub = threadIdx.x >> 5;             // 8 pixels per block iteration
+    const int sub = threadIdx.x >> 5;             // 8 pixel groups per block iteration
     const int c0 = 3 * l32;
     float wr[3][16], br[3], gw[3], gb[3];
 #pragma unroll
@@ -36,50 +39,75 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
         gw[c] = lnw[c0 + c];
         gb[c] = lnb[c0 + c];
     }
+    constexpr int GPR = kStemW / kStemPix;        // groups per output row (14)
     const long long stride = (long long)gridDim.x * 8;
-    const long long iters = (npix + stride - 1) / stride;      // uniform trip count (shuffles need full waves)
+    const long long iters = (ngroups + stride - 1) / stride;      // uniform trip count (shuffles need full waves)
     for (long long it = 0; it < iters; ++it) {
-        long long p = it * stride + (long long)blockIdx.x * 8 + sub;
-        const bool valid = p < npix;
-        if (!valid) p = npix - 1;
-        const int wcol = (int)(p % kStemW);
-        const long long bh = p / kStemW;
+        long long g = it * stride + (long long)blockIdx.x * 8 + sub;
+        const bool valid = g < ngroups;
+        if (!valid) g = ngroups - 1;
+        const int wg = (int)(g % GPR);
+        const long long bh = g / GPR;
         const int h = (int)(bh % H0);
         const long long b = bh / H0;
-        float acc[3] = {br[0], br[1], br[2]};
+        float4 xin[4][kStemPix];
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
-            const int t = 4 * h - 4 + ky;
-            if (t >= 0 && t < T) {
-                const float4 x = *reinterpret_cast<const float4*>(in + (b * T + t) * kMels + 4 * wcol);
+            int t = 4 * h - 4 + ky;
+            const bool rok = t >= 0 && t < T;
+            t = t < 0 ? 0 : (t >= T ? T - 1 : t);              // clamped address, zeroed below (no branchy loads)
+            const float4* rp = reinterpret_cast<const float4*>(in + (b * T + t) * kMels + 4 * kStemPix * wg);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    acc[c] = fmaf(x.x, wr[c][4 * ky + 0], acc[c]);
-                    acc[c] = fmaf(x.y, wr[c][4 * ky + 1], acc[c]);
-                    acc[c] = fmaf(x.z, wr[c][4 * ky + 2], acc[c]);
-                    acc[c] = fmaf(x.w, wr[c][4 * ky + 3], acc[c]);
-                }
+            for (int px = 0; px < kStemPix; ++px) {
+                float4 v = rp[px];
+                if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                xin[ky][px] = v;
             }
         }
-        const float mean = half_sum32(acc[0] + acc[1] + acc[2]) * (1.0f / 96.0f);
-        const float d0 = acc[0] - mean, d1 = acc[1] - mean, d2 = acc[2] - mean;
-        const float var = half_sum32(d0 * d0 + d1 * d1 + d2 * d2) * (1.0f / 96.0f);
-        const float rstd = 1.0f / sqrtf(var + 1e-6f);
+        float acc[kStemPix][3];
+#pragma unroll
+        for (int px = 0; px < kStemPix; ++px) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float a = br[c];
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    a = fmaf(xin[ky][px].x, wr[c][4 * ky + 0], a);
+                    a = fmaf(xin[ky][px].y, wr[c][4 * ky + 1], a);
+                    a = fmaf(xin[ky][px].z, wr[c][4 * ky + 2], a);
+                    a = fmaf(xin[ky][px].w, wr[c][4 * ky + 3], a);
+                }
+                acc[px][c] = a;
+            }
+        }
+        float mean[kStemPix], var[kStemPix];
+#pragma unroll
+        for (int px = 0; px < kStemPix; ++px) mean[px] = half_sum32(acc[px][0] + acc[px][1] + acc[px][2]) * (1.0f / 96.0f);
+#pragma unroll
+        for (int px = 0; px < kStemPix; ++px) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[px][c] -= mean[px];
+            var[px] = half_sum32(acc[px][0] * acc[px][0] + acc[px][1] * acc[px][1] + acc[px][2] * acc[px][2]) * (1.0f / 96.0f);
+        }
         if (valid) {
-            float* o = out + p * 96 + c0;
-            o[0] = fmaf(d0 * rstd, gw[0], gb[0]);
-            o[1] = fmaf(d1 * rstd, gw[1], gb[1]);
-            o[2] = fmaf(d2 * rstd, gw[2], gb[2]);
+            float* o = out + (g * kStemPix) * 96 + c0;
+#pragma unroll
+            for (int px = 0; px < kStemPix; ++px) {
+                const float rstd = 1.0f / sqrtf(var[px] + 1e-6f);
+                o[px * 96 + 0] = fmaf(acc[px][0] * rstd, gw[0], gb[0]);
+                o[px * 96 + 1] = fmaf(acc[px][1] * rstd, gw[1], gb[1]);
+                o[px * 96 + 2] = fmaf(acc[px][2] * rstd, gw[2], gb[2]);
+            }
         }
     }
 }
 
 int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, float* out, hipStream_t s) {
-    const long long npix = (long long)B * H0 * kStemW;
-    long long blocks = (npix + 7) / 8;
+    const long long ngroups = (long long)B * H0 * (kStemW / kStemPix);
+    long long blocks = (ngroups + 7) / 8;
     if (blocks > 8192) blocks = 8192;
     ProfScope ps(c, ACX_K_STEM, s);
-    stem_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, T, H0, npix, c->d_stem_w, c->d_stem_b,
+    stem_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, T, H0, ngroups, c->d_stem_w, c->d_stem_b,
                                                               c->d_stem_lnw, c->d_stem_lnb, out);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
