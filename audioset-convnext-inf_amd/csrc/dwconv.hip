@@ -16,6 +16,13 @@ constexpr int kDwSlice = 32;      // channels per workgroup (8 lanes x float4)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef ACX_LAB_DW_STAMP      // diagnostic build (tools/dw_lab.hip): where does a tile spend its cycles?
+__device__ unsigned long long acx_dw_stamps[8];
+#define ACX_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ACX_STAMP(var)
+#endif
+
 // Streaming form: a workgroup owns (clip, 32-channel slice, column strip of TW pixels, segment of row tiles)
 // and walks DOWN the image.  An LDS ring of TH+6 input rows is kept; each step computes TH output rows from
 // the ring while the next TH input rows are already in flight to registers (issued before the FMAs, written
@@ -32,19 +39,20 @@ struct DwCfg {
     static constexpr int kRowF4 = kCols * 8;                      // float4 per ring row
     static constexpr int kStepF4 = TH * kRowF4;                   // float4 fetched per step
     static constexpr int kStage = (kStepF4 + kThreads - 1) / kThreads;   // staging float4 per thread
-    static constexpr size_t kLdsBytes = (size_t)(kRing * kRowF4 + 49 * 8) * 16;
+    static constexpr size_t kLdsBytes = (size_t)(kRing * kRowF4 + 49 * 8 + 256) * 16;   // ring + weights + sinks
 };
 
 template <int TW, int TH>
 __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      const float* __restrict__ wt /*[49][C]*/,
-                                                      const float* __restrict__ bias, int H, int W, int C,
-                                                      int tiles_w, int tiles_h, int n_seg) {
+                                                         const float* __restrict__ wt /*[49][C]*/,
+                                                         const float* __restrict__ bias, int H, int W, int C,
+                                                         int tiles_w, int tiles_h, int n_seg) {
     using Cfg = DwCfg<TW, TH>;
     static_assert(Cfg::kThreads == 256, "thread mapping assumes 256 threads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* ring = reinterpret_cast<f32x4*>(smem);                  // [kRing][kCols][8]
     f32x4* wl = ring + Cfg::kRing * Cfg::kRowF4;                   // [49][8]
+    f32x4* dummy = wl + 49 * 8;                                    // [256] per-thread sink for out-of-image columns
 
     int bid = blockIdx.x;
     const int slice = bid % (C / kDwSlice); bid /= (C / kDwSlice);
@@ -54,69 +62,112 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
     const int c0 = slice * kDwSlice;
     const int w0 = tw * TW;
     const int tid = threadIdx.x;
-    // balanced segments of row tiles
-    const int t_begin = (int)((long long)tiles_h * seg / n_seg);
+    const int t_begin = (int)((long long)tiles_h * seg / n_seg);     // balanced segments of row tiles
     const int t_end = (int)((long long)tiles_h * (seg + 1) / n_seg);
     if (t_begin >= t_end) return;
 
     for (int i = tid; i < 49 * 8; i += Cfg::kThreads)
         wl[i] = *reinterpret_cast<const f32x4*>(wt + (i >> 3) * C + c0 + 4 * (i & 7));
+    // columns outside the image are never written again: zero the whole ring once
+    for (int i = tid; i < Cfg::kRing * Cfg::kRowF4; i += Cfg::kThreads) ring[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* xb = x + b * (long long)H * W * C + c0;
+    const long long row_elems = (long long)W * C;
 
-    // staging coordinates of this thread's float4 #k within a step of TH rows: (row, col, quad).
-    // Loads are UNCONDITIONAL on clamped (always valid) addresses and zero-padding is applied when the
-    // registers are written to the ring: a per-element "load or zero" makes hipcc branch around every load
-    // and wait for all of them right there, which would serialise the prefetch with the FMAs.
-    int st_row[Cfg::kStage], st_off[Cfg::kStage];
-    unsigned col_ok = 0;                                // bit k: column inside the image and slot in range
+    // Per-thread staging plan for a step of TH image rows (float4 #k of this thread):
+    //   st_ptr[k]  source of (row st_row[k], column, quad) for image row 0   (columns clamped into the image)
+    //   st_lds[k]  float4 index inside a ring row, or -1 - (dummy index) when the column is outside the image
+    // Loads are UNCONDITIONAL on valid addresses (a per-element "load or zero" makes hipcc branch around every
+    // load and wait for all of them on the spot); rows outside the image only occur in the first/last step of a
+    // column and take the slow (clamp + zero) path, selected by a wave-uniform test.
+    const float* st_ptr[Cfg::kStage];
+    int st_row[Cfg::kStage], st_lds[Cfg::kStage];
 #pragma unroll
     for (int k = 0; k < Cfg::kStage; ++k) {
-        const int i = tid + k * Cfg::kThreads;
+        int i = tid + k * Cfg::kThreads;
+        const bool in_step = i < Cfg::kStepF4;
+        if (!in_step) i = Cfg::kStepF4 - 1;
         const int qq = i & 7;
         const int col = (i >> 3) % Cfg::kCols;
-        st_row[k] = (i < Cfg::kStepF4) ? (i >> 3) / Cfg::kCols : 0;
+        st_row[k] = (i >> 3) / Cfg::kCols;
         const int gw = w0 - 3 + col;
         const int gwc = gw < 0 ? 0 : (gw >= W ? W - 1 : gw);
-        st_off[k] = gwc * C + 4 * qq;
-        if (i < Cfg::kStepF4 && gw >= 0 && gw < W) col_ok |= 1u << k;
+        st_ptr[k] = xb + st_row[k] * row_elems + gwc * C + 4 * qq;
+        st_lds[k] = (in_step && gw >= 0 && gw < W) ? (col * 8 + qq) : -1;
     }
     const int g_origin = t_begin * TH - 3;             // image row kept in ring row 0 of this segment
     f32x4 rg[Cfg::kStage];
-#define ACX_DW_LOAD(first_row)  /* image rows first_row .. +TH-1 -> registers (row index clamped) */      \
+#define ACX_DW_LOAD_FAST(first_row)   /* rows first_row .. +TH-1, all inside the image */                    \
+    {                                                                                                     \
+        const long long roff = (long long)(first_row) * row_elems;                                        \
+        _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k)                                           \
+            rg[k] = *reinterpret_cast<const f32x4*>(st_ptr[k] + roff);                                    \
+    }
+#define ACX_DW_LOAD_EDGE(first_row)   /* some rows outside [0,H): clamp the row, zero at store time */      \
     _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {                                             \
         int gh = (first_row) + st_row[k];                                                                 \
         gh = gh < 0 ? 0 : (gh >= H ? H - 1 : gh);                                                         \
-        rg[k] = *reinterpret_cast<const f32x4*>(xb + (long long)gh * W * C + st_off[k]);                  \
+        rg[k] = *reinterpret_cast<const f32x4*>(st_ptr[k] + (long long)(gh - st_row[k]) * row_elems);     \
     }
-#define ACX_DW_STORE(first_row, max_rows) /* registers -> ring rows, zero outside the image */            \
-    _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {                                             \
-        const int i = tid + k * Cfg::kThreads;                                                            \
-        if (i < Cfg::kStepF4 && st_row[k] < (max_rows)) {                                                 \
-            const int gh = (first_row) + st_row[k];                                                       \
-            const bool ok = ((col_ok >> k) & 1u) && gh >= 0 && gh < H;                                    \
-            const int slot = (gh - g_origin) % Cfg::kRing;                                                \
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};                                                         \
-            ring[slot * Cfg::kRowF4 + (i - st_row[k] * Cfg::kRowF4)] = ok ? rg[k] : z;                    \
+#define ACX_DW_STORE(first_row, max_rows, edge) /* registers -> ring rows of image rows first_row .. */     \
+    {                                                                                                     \
+        const int slot0 = ((first_row) - g_origin) % Cfg::kRing;           /* wave-uniform */             \
+        _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {                                         \
+            int slot = slot0 + st_row[k];                                                                 \
+            if (slot >= Cfg::kRing) slot -= Cfg::kRing;                                                   \
+            f32x4 v = rg[k];                                                                              \
+            bool keep = st_lds[k] >= 0 && st_row[k] < (max_rows);                                         \
+            if (edge) {                                                                                   \
+                const int gh = (first_row) + st_row[k];                                                   \
+                if (gh < 0 || gh >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};                                     \
+            }                                                                                             \
+            f32x4* dst = keep ? ring + slot * Cfg::kRowF4 + st_lds[k] : dummy + tid;                      \
+            *dst = v;                                                                                     \
         }                                                                                                 \
     }
+    __syncthreads();                                   // ring zeroed before the prologue fills it
     // prologue: image rows [g_origin, g_origin + TH + 6) in two rounds (of the second only 6 rows are kept)
-    ACX_DW_LOAD(g_origin)
-    ACX_DW_STORE(g_origin, TH)
-    ACX_DW_LOAD(g_origin + TH)
-    ACX_DW_STORE(g_origin + TH, 6)
+    ACX_DW_LOAD_EDGE(g_origin)
+    ACX_DW_STORE(g_origin, TH, true)
+    ACX_DW_LOAD_EDGE(g_origin + TH)
+    ACX_DW_STORE(g_origin + TH, 6, true)
     __syncthreads();
 
     const int q = tid & 7;
     const int strip = (tid >> 3) % Cfg::kStrips;
     const int r = (tid >> 3) / Cfg::kStrips;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0 + 4 * q);
+    const int rd_off = (strip * Cfg::WT) * 8 + q;      // float4 offset of this thread's first input column
+    float* const yb = y + ((b * H) * (long long)W + w0 + strip * Cfg::WT) * C + c0 + 4 * q;
 
+#ifdef ACX_LAB_DW_STAMP
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, acc_s[5] = {0, 0, 0, 0, 0};
+#endif
+    f32x4 so[Cfg::WT];
+#pragma unroll
+    for (int i = 0; i < Cfg::WT; ++i) so[i] = bv;
+    float* yp_prev = nullptr;                          // where so[] belongs (null: nothing pending)
+#ifdef ACX_LAB_DW_NOSTORE
+#define ACX_DW_FLUSH if (yp_prev != nullptr && so[0][0] == 12345.678f) { _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x4*>(yp_prev + (long long)i * C) = so[i]; }
+#else
+#define ACX_DW_FLUSH if (yp_prev != nullptr) { _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x4*>(yp_prev + (long long)i * C) = so[i]; }
+#endif
     for (int t = t_begin; t < t_end; ++t) {
         const int h0 = t * TH;
         const bool more = t + 1 < t_end;
-        // next step's rows: image rows h0 + TH + 3 .. h0 + 2TH + 2  (ring rows of the TH oldest)
-        const int next_first = h0 + TH + 3;
-        ACX_DW_LOAD(next_first)           // (on the last tile of the segment: a discarded, in-range load)
+        ACX_STAMP(ts0)
+        const int next_first = h0 + TH + 3;            // image rows of the next step (ring rows of the TH oldest)
+        const bool edge = next_first + TH > H;         // (next_first >= 0 always)
+#ifndef ACX_LAB_DW_NOLOAD
+        if (more) {
+            if (edge) { ACX_DW_LOAD_EDGE(next_first) } else { ACX_DW_LOAD_FAST(next_first) }
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // Outputs leave one tile LATE, from their own register set, right BEHIND the next prefetch: hipcc puts a
+        // vmcnt(0) in front of the prefetch address set-up (it cannot prove the staging registers idle across
+        // the back edge), so nothing may be in flight there; the one real wait of the loop (before the ring
+        // refill) then covers loads and stores that both had a whole FMA phase to complete.
+        ACX_DW_FLUSH
         __builtin_amdgcn_sched_barrier(0);
 
         f32x4 acc[Cfg::WT];
@@ -127,76 +178,117 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
         const int base = (h0 - 3 - g_origin + r) % Cfg::kRing;    // ring slot of input row h0 - 3 + r
         // The 7 kernel rows are software-pipelined by hand in HALF rows: the LDS reads of the next unit
         // (7 or 6 input float4, and once per row the 7 weight float4 of the next kernel row) are issued into
-        // a second register set BEFORE the 49 packed FMAs of the current unit.  With two waves per SIMD there
-        // is not enough TLP to cover an LDS round trip per kernel row otherwise (the rolled loop spent 55 % of
-        // its wave time in s_waitcnt).  Half rows keep the double buffers at 112 VGPRs.
+        // a second register set BEFORE the 49 packed FMAs of the current unit.  A wave issues at most one
+        // instruction per ~5 cycles and only two waves fit per SIMD, so every non-FMA instruction costs FMA
+        // time: one wait per unit (single asm touch), no per-element address math.
         f32x4 iA[7], iB[6], wA[7], wB[7];
 #define ACX_DW_ROWP(ky_, p_)                                                                              \
         const f32x4* p_;                                                                                  \
         {                                                                                                 \
             int slot = base + (ky_);                                                                      \
             if (slot >= Cfg::kRing) slot -= Cfg::kRing;                                                   \
-            p_ = ring + (slot * Cfg::kCols + strip * Cfg::WT) * 8 + q;                                    \
+            p_ = ring + slot * Cfg::kRowF4 + rd_off;                                                      \
         }
 #define ACX_DW_READ_W(w_, ky_) _Pragma("unroll") for (int kx = 0; kx < 7; ++kx) w_[kx] = wl[((ky_) * 7 + kx) * 8 + qw];
 #define ACX_DW_READ_I0(ky_) { ACX_DW_ROWP(ky_, p0_) _Pragma("unroll") for (int j = 0; j < 7; ++j) iA[j] = p0_[j * 8]; }
 #define ACX_DW_READ_I1(ky_) { ACX_DW_ROWP(ky_, p1_) _Pragma("unroll") for (int j = 0; j < 6; ++j) iB[j] = p1_[(7 + j) * 8]; }
-#define ACX_DW_PIN _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) asm volatile("" : "+v"(acc[i]));
+#ifdef ACX_LAB_DW_SCALAR_FMA
+#define ACX_DW_MAC(a_, i_, w_)                                                                             \
+        {                                                                                                 \
+            float t0, t1, t2, t3;                                                                         \
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(i_[0]), "v"(w_[0]), "v"(a_[0]));     \
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(i_[1]), "v"(w_[1]), "v"(a_[1]));     \
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t2) : "v"(i_[2]), "v"(w_[2]), "v"(a_[2]));     \
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(i_[3]), "v"(w_[3]), "v"(a_[3]));     \
+            a_[0] = t0; a_[1] = t1; a_[2] = t2; a_[3] = t3;                                               \
+        }
+#else
+#define ACX_DW_MAC(a_, i_, w_) a_ += i_ * w_;
+#endif
         // opaque re-definition of acc pins the FMAs in place (plain arithmetic is otherwise sunk below later reads)
+#define ACX_DW_PIN asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]));
 #define ACX_DW_FMA0(w_)                                                                                   \
         {                                                                                                 \
             _Pragma("unroll") for (int j = 0; j < 7; ++j)                                                 \
-            _Pragma("unroll") for (int kx = 0; kx <= j; ++kx) acc[j - kx] += iA[j] * w_[kx];              \
+            _Pragma("unroll") for (int kx = 0; kx <= j; ++kx) ACX_DW_MAC(acc[j - kx], iA[j], w_[kx])      \
             ACX_DW_PIN                                                                                    \
         }
 #define ACX_DW_FMA1(w_)                                                                                   \
         {                                                                                                 \
             _Pragma("unroll") for (int j = 7; j < 13; ++j)                                                \
-            _Pragma("unroll") for (int kx = j - 6; kx < 7; ++kx) acc[j - kx] += iB[j - 7] * w_[kx];       \
+            _Pragma("unroll") for (int kx = j - 6; kx < 7; ++kx) ACX_DW_MAC(acc[j - kx], iB[j - 7], w_[kx]) \
             ACX_DW_PIN                                                                                    \
         }
-#define ACX_DW_TOUCH(arr_, n_) _Pragma("unroll") for (int z = 0; z < (n_); ++z) asm volatile("" :: "v"(arr_[z]));
+        // one asm statement per register set: ONE lgkmcnt wait, placed in front of the next batch of reads
+#define ACX_DW_TOUCH6(a_) asm volatile("" :: "v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]), "v"(a_[4]), "v"(a_[5]));
+#define ACX_DW_TOUCH7(a_) asm volatile("" :: "v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]), "v"(a_[4]), "v"(a_[5]), "v"(a_[6]));
+        // LDS reads are SPREAD between the FMAs (sched_group_barrier: 1 ds_read, then a few VALU, repeated):
+        // eight waves bursting 14 reads each overflow the LDS queue and stall the issuing waves.
+#define ACX_DW_MIX(nread_, nvalu_)                                                                        \
+        _Pragma("unroll") for (int z = 0; z < (nread_); ++z) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
+            __builtin_amdgcn_sched_group_barrier(0x002, (nvalu_), 0);                                     \
+        }
 #define ACX_DW_KROW(ky_, wc_, wn_)   /* kernel row ky_ with weights wc_; prefetches row ky_+1 into wn_ */   \
         {                                                                                                 \
             ACX_DW_READ_I1(ky_)                                                                           \
-            __builtin_amdgcn_sched_barrier(0);                                                            \
             ACX_DW_FMA0(wc_)                                                                              \
+            ACX_DW_MIX(6, 9)                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                            \
-            ACX_DW_TOUCH(iB, 6)                                                                           \
+            ACX_DW_TOUCH6(iB)                                                                             \
             if ((ky_) + 1 < 7) { ACX_DW_READ_W(wn_, (ky_) + 1) ACX_DW_READ_I0((ky_) + 1) }                \
-            __builtin_amdgcn_sched_barrier(0);                                                            \
             ACX_DW_FMA1(wc_)                                                                              \
+            if ((ky_) + 1 < 7) { ACX_DW_MIX(14, 3) }                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                            \
-            if ((ky_) + 1 < 7) { ACX_DW_TOUCH(wn_, 7) ACX_DW_TOUCH(iA, 7) }                               \
+            if ((ky_) + 1 < 7) { ACX_DW_TOUCH7(wn_) ACX_DW_TOUCH7(iA) }                                   \
         }
         ACX_DW_READ_W(wA, 0)
         ACX_DW_READ_I0(0)
+#ifndef ACX_LAB_DW_NOFMA
         ACX_DW_KROW(0, wA, wB) ACX_DW_KROW(1, wB, wA) ACX_DW_KROW(2, wA, wB) ACX_DW_KROW(3, wB, wA)
         ACX_DW_KROW(4, wA, wB) ACX_DW_KROW(5, wB, wA) ACX_DW_KROW(6, wA, wB)
+#endif
 #undef ACX_DW_ROWP
 #undef ACX_DW_READ_W
 #undef ACX_DW_READ_I0
 #undef ACX_DW_READ_I1
 #undef ACX_DW_PIN
+#undef ACX_DW_MAC
 #undef ACX_DW_FMA0
 #undef ACX_DW_FMA1
-#undef ACX_DW_TOUCH
+#undef ACX_DW_TOUCH6
+#undef ACX_DW_TOUCH7
 #undef ACX_DW_KROW
-        const int h = h0 + r;
-        if (h < H) {
-            float* yp = y + ((b * H + h) * (long long)W + w0 + strip * Cfg::WT) * C + c0 + 4 * q;
-#pragma unroll
-            for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x4*>(yp + (long long)i * C) = acc[i];
-        }
+#undef ACX_DW_MIX
+        ACX_STAMP(ts1)
         __builtin_amdgcn_sched_barrier(0);
+        ACX_STAMP(ts2)
         if (more) {
             __syncthreads();                                       // everyone is done reading the ring
+            ACX_STAMP(ts3)
             asm volatile("" : "+v"(rg[0]));                        // keep the vmcnt wait down here
-            ACX_DW_STORE(next_first, TH)
+            if (edge) { ACX_DW_STORE(next_first, TH, true) } else { ACX_DW_STORE(next_first, TH, false) }
+            ACX_STAMP(ts4)
             __syncthreads();
+            ACX_STAMP(ts5)
+#ifdef ACX_LAB_DW_STAMP
+            acc_s[0] += ts1 - ts0; acc_s[1] += ts2 - ts1; acc_s[2] += ts3 - ts2; acc_s[3] += ts4 - ts3; acc_s[4] += ts5 - ts4;
+#endif
         }
+#pragma unroll
+        for (int i = 0; i < Cfg::WT; ++i) so[i] = acc[i];
+        yp_prev = (h0 + r < H) ? yb + (long long)(h0 + r) * row_elems : nullptr;
     }
-#undef ACX_DW_LOAD
+    ACX_DW_FLUSH
+#undef ACX_DW_FLUSH
+#ifdef ACX_LAB_DW_STAMP
+    if ((tid & 63) == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&acx_dw_stamps[i], acc_s[i]);
+        atomicAdd(&acx_dw_stamps[5], (unsigned long long)(t_end - t_begin - 1));
+    }
+#endif
+#undef ACX_DW_LOAD_FAST
+#undef ACX_DW_LOAD_EDGE
 #undef ACX_DW_STORE
 }
 
