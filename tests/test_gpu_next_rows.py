@@ -1,0 +1,78 @@
+"""GPU (`-m gpu`): the "next" rows end to end on the HIP path -- evaluation harness, variable-length
+extraction, the demo script -- against the CPU oracle on the same seeded inputs."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from audioset_convnext_inf_amd import synth
+from audioset_convnext_inf_amd.pytorch import evaluate as ev
+from audioset_convnext_inf_amd.pytorch.convnext import convnext_tiny
+from audioset_convnext_inf_amd.pytorch.extract_embeddings import extract
+from audioset_convnext_inf_amd.utils import utilities as ut
+from audioset_convnext_inf_amd.utils.data_generator import ClipShard, evaluate_batches
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model(synth_sd):
+    m = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
+                      use_speed_perturb=False)
+    m.load_state_dict(synth_sd)
+    return m.to("cuda").eval()
+
+
+def test_evaluator_matches_oracle(model, synth_sd):
+    from oracle import ref_cpu
+    rs = np.random.RandomState(5)
+    n, L = 23, 32000                                   # 3 batches of 10, the last one short
+    wav = (rs.standard_normal((n, L)) * 0.1 * 32767).astype(np.int16)
+    tgt = rs.uniform(size=(n, 527)) < 0.3
+    tgt[0], tgt[1] = True, False
+    shard = ClipShard(wav, tgt)
+    out = ev.forward(model, evaluate_batches(shard, batch_size=10), return_target=True)
+    assert out["clipwise_output"].shape == (n, 527) and out["target"].shape == (n, 527)
+    ref = ref_cpu.forward(synth_sd, torch.from_numpy(ut.int16_to_float32(wav)))["clipwise_output"].numpy()
+    assert np.abs(out["clipwise_output"] - ref).max() < 1e-3          # BASELINE tolerance on probs
+    stats = ev.Evaluator(model).evaluate(evaluate_batches(shard, batch_size=10))
+    ref_stats = ev.calculate_statistics(tgt.astype(np.float32), ref)
+    assert abs(np.mean(stats["average_precision"]) - np.mean(ref_stats["average_precision"])) < 2e-3
+    assert abs(np.mean(stats["auc"]) - np.mean(ref_stats["auc"])) < 2e-3
+    one = ev.evaluate_sharded(model, shard, batch_size=10)            # world_size 1 path of the sharded sweep
+    np.testing.assert_allclose(one["average_precision"], stats["average_precision"])
+
+
+def test_variable_length_extraction(model, synth_sd):
+    from oracle import ref_cpu
+    lengths = [7360, 9600, 7360, 32000, 9600]
+    clips = [synth.synth_waveforms(1, n, seed=100 + i)[0] for i, n in enumerate(lengths)]
+    got = extract(model, clips, "logits")
+    frames = extract(model, clips, "frame")
+    for i, (c, n) in enumerate(zip(clips, lengths)):
+        solo = model(c[None].cuda())["clipwise_logits"][0].cpu()
+        assert torch.equal(got[i], solo)                               # bucketing does not change a clip's result
+        assert frames[i].shape == (768, ref_cpu.out_hw(n)[3][0], 7)
+    ref = ref_cpu.forward(synth_sd, clips[3][None])["clipwise_logits"][0]
+    assert float((got[3] - ref).abs().max()) < 1e-3
+
+
+def test_demo_script(tmp_path):
+    rs = np.random.RandomState(0)
+    wav = str(tmp_path / "clip.wav")
+    ut.write_wav_pcm16(wav, (rs.standard_normal(48000) * 0.1).astype(np.float32), 32000, list_chunk=True)
+    labels = tmp_path / "labels.csv"
+    labels.write_text("index,mid,display_name\n" + "".join('%d,/m/%04d,"label %d"\n' % (i, i, i) for i in range(527)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "demo_convnext.py"), "--synthetic-weights", "--wav", wav,
+                        "--labels", str(labels)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+    assert "# params: 28222767" in out                                  # README.md:49
+    assert "logits size: torch.Size([1, 527])" in out and "probs size: torch.Size([1, 527])" in out
+    assert "Scene embedding, shape: torch.Size([1, 768])" in out
+    assert "Frame-level embeddings, shape: torch.Size([1, 768, 31, 7])" in out   # padded to 10 s
+    assert "Padding waveform" in out and "label " in out

@@ -1,0 +1,94 @@
+"""CPU: the components either side of the hot path: label map, PCM scaling, WAV reading,
+evaluation batching and metrics, length bucketing."""
+import numpy as np
+import pytest
+import torch
+
+from audioset_convnext_inf_amd.pytorch import evaluate as ev
+from audioset_convnext_inf_amd.pytorch.extract_embeddings import bucket_by_length
+from audioset_convnext_inf_amd.utils import utilities as ut
+from audioset_convnext_inf_amd.utils.data_generator import ClipShard, EvaluateSampler, evaluate_batches
+
+
+def test_label_tags(tmp_path):
+    p = tmp_path / "labels.csv"
+    p.write_text('index,mid,display_name\n0,/m/09x0r,"Speech"\n1,/m/05zppz,"Male speech, man speaking"\n2,/m/04rlf,"Music"\n')
+    lb_to_ix, ix_to_lb, id_to_ix, ix_to_id = ut.read_audioset_label_tags(str(p))
+    assert ix_to_lb == {0: "Speech", 1: "Male speech, man speaking", 2: "Music"}
+    assert lb_to_ix["Music"] == 2 and id_to_ix["/m/09x0r"] == 0 and ix_to_id[1] == "/m/05zppz"
+
+
+def test_pcm_scaling_conventions():
+    x = np.array([-32768, -1, 0, 1, 32767], dtype=np.int16)
+    np.testing.assert_array_equal(ut.int16_to_float32(x), (x / 32767.0).astype(np.float32))      # HDF5 path
+    assert ut.float32_to_int16(np.array([2.0, -2.0, 0.5])).tolist() == [32767, -32767, 16383]
+    assert ut.pad_or_truncate(np.arange(3), 5).tolist() == [0, 1, 2, 0, 0]
+    assert ut.pad_or_truncate(np.arange(7), 5).tolist() == [0, 1, 2, 3, 4]
+
+
+def test_wav_reader_with_list_chunk(tmp_path):
+    rs = np.random.RandomState(0)
+    w = (rs.randint(-32768, 32767, size=5000) / 32768.0).astype(np.float32)
+    for list_chunk in (False, True):
+        p = str(tmp_path / ("a%d.wav" % list_chunk))
+        ut.write_wav_pcm16(p, w, 32000, list_chunk=list_chunk)
+        got, sr = ut.read_wav_pcm16(p)
+        assert sr == 32000 and got.shape == (1, 5000)
+        np.testing.assert_array_equal(got[0], w)                    # /32768, the torchaudio.load convention
+    clip = ut.prepare_clip(torch.from_numpy(got), 32000)
+    assert clip.shape == (1, 320000) and float(clip[0, 5000:].abs().max()) == 0.0
+    long = ut.prepare_clip(torch.zeros(1, 400000), 32000)
+    assert long.shape == (1, 320000)
+    assert ut.prepare_clip(torch.zeros(1, 16000), 16000).shape == (1, 320000)      # resampled then padded
+
+
+def test_sampler_batches_and_sharding():
+    assert [b.tolist() for b in EvaluateSampler(7, 3)] == [[0, 1, 2], [3, 4, 5], [6]]          # short last batch
+    a = [b.tolist() for b in EvaluateSampler(10, 3, rank=0, world_size=2)]
+    b = [b.tolist() for b in EvaluateSampler(10, 3, rank=1, world_size=2)]
+    assert a == [[0, 1, 2], [6, 7, 8]] and b == [[3, 4, 5], [9]]
+    assert len(EvaluateSampler(10, 3, 0, 2)) == 2 and len(EvaluateSampler(10, 3, 1, 2)) == 2
+    shard = ClipShard(np.arange(40, dtype=np.int16).reshape(5, 8), np.eye(5, 527, dtype=bool))
+    batches = list(evaluate_batches(shard, batch_size=2))
+    assert [x["waveform"].shape for x in batches] == [(2, 8), (2, 8), (1, 8)]
+    assert batches[0]["waveform"].dtype == np.float32 and batches[0]["target"].dtype == np.float32
+    np.testing.assert_allclose(batches[2]["waveform"][0], np.arange(32, 40) / 32767.0, rtol=1e-7)
+
+
+class _Scorer(torch.nn.Module):
+    """Deterministic stand-in model: score of class c = sigmoid(mean(x) * (c+1))."""
+
+    def __init__(self):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        z = x.mean(1, keepdim=True) * torch.arange(1, 528, dtype=torch.float32)[None]
+        return {"clipwise_output": torch.sigmoid(z), "clipwise_logits": z}
+
+
+def test_evaluator_statistics_match_sklearn():
+    from math import sqrt
+    from scipy.stats import norm
+    from sklearn import metrics
+    rs = np.random.RandomState(1)
+    wav = (rs.standard_normal((37, 64)) * 3000).astype(np.int16)
+    tgt = rs.uniform(size=(37, 527)) < 0.3
+    tgt[0], tgt[1] = True, False
+    shard = ClipShard(wav, tgt)
+    stats = ev.Evaluator(_Scorer()).evaluate(evaluate_batches(shard, batch_size=8))
+    x = torch.from_numpy(wav / np.float32(32767.0)).float()
+    scores = _Scorer()(x)["clipwise_output"].numpy()
+    np.testing.assert_allclose(stats["average_precision"], metrics.average_precision_score(tgt.astype(np.float32), scores, average=None))
+    auc = metrics.roc_auc_score(tgt.astype(np.float32), scores, average=None)
+    np.testing.assert_allclose(stats["auc"], auc)
+    np.testing.assert_allclose(stats["d_prime"], sqrt(2) * norm.ppf(auc))
+    assert stats["average_precision"].shape == (527,)
+    # object-dtype batches (the reference's collate_fn output) are cast, not passed through
+    obj = np.empty(2, dtype=object)
+    obj[0], obj[1] = np.zeros(4), np.ones(4)
+    assert ev.move_data_to_device(obj, "cpu").dtype == torch.float32
+
+
+def test_bucket_by_length():
+    assert bucket_by_length([10, 20, 10, 30, 20]) == {10: [0, 2], 20: [1, 4], 30: [3]}
