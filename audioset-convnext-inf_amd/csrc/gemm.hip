@@ -60,8 +60,8 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, char* lds_wave_base
 }
 
 // GATHER: 0 plain rows, 1 2x2 patch gather (downsample)
-template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+template <int kBM, int BN, int WM, int WN, int EPI, int GATHER, int DW>
+__global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
     constexpr int TM = kBM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr int A_TILE = kBM * kRowBytes, B_TILE = BN * kRowBytes;     // bytes
@@ -90,8 +90,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const long long m0 = tile_m * kBM;
     const int n0 = tile_n * BN;
 
-    // ---- LDS-DMA source pointers: wave w stages rows [R*w, R*w+R) of each tile, 8 rows per piece ------
     const int prow = lane >> 3, pchunk = lane & 7;
+    if (DW && wave == 4) {
+        // ---- dedicated LDS-DMA wave: issues every 1-KB piece of both operand tiles, so the four MFMA waves
+        //      never spend issue slots on loads (an LDS-DMA costs 60-180 cycles of issue, MI355X_MICROARCH.md) --
+        constexpr int AP = kBM / 8, BP = BN / 8;
+        const float* a_all[AP];
+        const float* b_all[BP];
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int row = 8 * i + prow;
+            const int chunk = pchunk ^ ((row >> 1) & 7);
+            long long m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            if (GATHER) {
+                const int wo = (int)(m % p.Wo);
+                const long long t = m / p.Wo;
+                const int ho = (int)(t % p.Ho);
+                const long long b = t / p.Ho;
+                a_all[i] = p.A + ((b * p.H + 2 * ho) * p.W + 2 * wo) * p.C + 4 * chunk;
+            } else {
+                a_all[i] = p.A + m * p.K + 4 * chunk;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int row = 8 * i + prow;
+            const int chunk = pchunk ^ ((row >> 1) & 7);
+            b_all[i] = p.Wt + (long long)(n0 + row) * p.K + 4 * chunk;
+        }
+        const int nkd = p.K / kBK;
+        for (int kt = 0; kt < nkd; ++kt) {
+            const int k0 = kt * kBK;
+            long long koff = k0;
+            if (GATHER) {
+                const int qd = k0 / p.C;
+                koff = (long long)((qd >> 1) * p.W + (qd & 1)) * p.C + (k0 - qd * p.C);
+            }
+            char* ad = As + (kt & 1) * A_TILE;
+            char* bd = Bs + (kt & 1) * B_TILE;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) lds_dma16(a_all[i] + koff, ad + i * 1024);
+#pragma unroll
+            for (int i = 0; i < BP; ++i) lds_dma16(b_all[i] + k0, bd + i * 1024);
+            __syncthreads();      // (hipcc drains the LDS-DMA first) pairs with the MFMA waves' barrier of tile kt
+        }
+        return;
+    }
+    // ---- LDS-DMA source pointers: wave w stages rows [R*w, R*w+R) of each tile, 8 rows per piece ------
     const float* a_src[A_DMA];
 #pragma unroll
     for (int i = 0; i < A_DMA; ++i) {
@@ -172,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 
     const int nk = p.K / kBK;
-    ACX_DMA_TILE(0, 0);
+    if (!DW) ACX_DMA_TILE(0, 0);
     __syncthreads();          // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
     // Software pipeline over k-tiles, ONE barrier per tile, placed BEFORE the last MFMA group so that
     // every wave leaves it with 4*TM*TN MFMAs already fed (barrier skew and the first LDS reads of the
@@ -192,7 +238,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
         const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
 #ifndef ACX_LAB_NO_GLOBAL
-        ACX_DMA_TILE((kt + 1) * kBK, (kt + 1) & 1);
+        if (!DW) ACX_DMA_TILE((kt + 1) * kBK, (kt + 1) & 1);
 #endif
         __builtin_amdgcn_sched_barrier(0);
         ACX_MFMA_GROUP(af0, bf0)
@@ -295,8 +341,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 template <int BM, int BN>
 constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * kRowBytes; }
 
+// ACX_GEMM_DW=1 builds the variant with a 5th, dedicated LDS-DMA wave.  Measured NEGATIVE on MI355X (tools/
+// gemm_lab: s2.pw1 657 vs 581 us, s2.pw2 742 vs 627 us): one wave cannot issue the 32 pieces of a tile and see
+// them land within one k-tile of MFMA time, so it becomes the critical path; 8 pieces on each MFMA wave is faster.
+#ifndef ACX_GEMM_DW
+#define ACX_GEMM_DW 0
+#endif
 template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
 static int launch_cfg(const GemmParams& p0, hipStream_t s) {
+    constexpr int DW = ACX_GEMM_DW;
     GemmParams p = p0;
     p.tiles_n = p.N / BN;
     const long long tiles_m = (p.M + kBM - 1) / kBM;
@@ -304,11 +357,11 @@ static int launch_cfg(const GemmParams& p0, hipStream_t s) {
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm: grid too large");
     static bool attr_set = false;
     if (!attr_set) {
-        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER>),
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER, DW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<kBM, BN>()));
         attr_set = true;
     }
-    gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(256), gemm_lds_bytes<kBM, BN>(), s>>>(p);
+    gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER, DW><<<dim3((unsigned)blocks), dim3(256 + 64 * DW), gemm_lds_bytes<kBM, BN>(), s>>>(p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
