@@ -24,6 +24,13 @@ namespace acx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef ACX_LAB_GEMM_STAMP    // diagnostic build (tools/gemm_lab.hip): cycle shares of a k-tile
+__device__ unsigned long long acx_gemm_stamps[8];
+#define ACX_GSTAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ACX_GSTAMP(var)
+#endif
+
 constexpr int kBK = 32;
 constexpr int kRowBytes = kBK * 4;        // 128-B LDS rows
 
@@ -206,6 +213,24 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[i][e], bf_[j][e], acc[i][j], 0, 0, 0); \
     }
+    // MFMA group with the LDS-DMA of the NEXT tile threaded through it: one 1-KB piece in front of each of the
+    // 4 k-steps (A pieces in group g0, B pieces in group g1).  Issued as a burst of 8 at the top of the tile,
+    // the DMAs stall the wave for ~1k cycles while its SIMD partner -- which runs the same program and has
+    // drifted into lockstep through MFMA-pipe contention -- stalls on its own burst at the same moment.
+#define ACX_MFMA_GROUP_DMA(af_, bf_, src_, n_, koff_, dst_)                                            \
+    {                                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
+            if (!DW && e < (n_)) {                                                                     \
+                lds_dma16(src_[e] + (koff_), (dst_) + e * 8 * kRowBytes);                              \
+                __builtin_amdgcn_sched_barrier(0);                                                     \
+            }                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[i][e], bf_[j][e], acc[i][j], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+        }                                                                                              \
+    }
+    static_assert(A_DMA <= 4 && B_DMA <= 4, "at most 4 DMA pieces per operand per wave are threaded through a group");
     static_assert(kBK == 32, "the tile schedule below is written for 4 k-groups of 8");
     // With an LDS-DMA in flight hipcc (ROCm 7.2) no longer emits counted lgkmcnt(N) waits, only lgkmcnt(0).
     // An opaque use of the fragments the NEXT MFMA group needs, placed right after the current group (their
@@ -232,21 +257,39 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
         ACX_READ_FRAGS(af0, bf0, ab, bb, 0)
         ACX_READ_FRAGS(af1, bf1, ab, bb, 1)
     }
+#ifdef ACX_LAB_GEMM_STAMP
+    unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, gs[4] = {0, 0, 0, 0}, gk0 = 0, gk1 = 0;
+    ACX_GSTAMP(gk0)
+#endif
     for (int kt = 0; kt + 1 < nk; ++kt) {
+        ACX_GSTAMP(g0)
         const char* ab = As + (kt & 1) * A_TILE + a_frag_off;
         const char* bb = Bs + (kt & 1) * B_TILE + b_frag_off;
         const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
         const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
-#ifndef ACX_LAB_NO_GLOBAL
-        if (!DW) ACX_DMA_TILE((kt + 1) * kBK, (kt + 1) & 1);
-#endif
+        const int k1 = (kt + 1) * kBK;
+        long long koff1 = k1;
+        if (GATHER) {
+            const int qd = k1 / p.C;
+            koff1 = (long long)((qd >> 1) * p.W + (qd & 1)) * p.C + (k1 - qd * p.C);
+        }
+        char* adn = a_dst + ((kt + 1) & 1) * A_TILE;
+        char* bdn = b_dst + ((kt + 1) & 1) * B_TILE;
         __builtin_amdgcn_sched_barrier(0);
+#ifndef ACX_LAB_NO_GLOBAL
+        ACX_MFMA_GROUP_DMA(af0, bf0, a_src, A_DMA, koff1, adn)
+#else
         ACX_MFMA_GROUP(af0, bf0)
+#endif
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af1, bf1)       // see ACX_TOUCH: drain the OLD reads before issuing new ones
         ACX_READ_FRAGS(af0, bf0, ab, bb, 2)
         __builtin_amdgcn_sched_barrier(0);
+#ifndef ACX_LAB_NO_GLOBAL
+        ACX_MFMA_GROUP_DMA(af1, bf1, b_src, B_DMA, (long long)k1, bdn)
+#else
         ACX_MFMA_GROUP(af1, bf1)
+#endif
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af0, bf0)
         ACX_READ_FRAGS(af1, bf1, ab, bb, 3)
@@ -254,14 +297,23 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
         ACX_MFMA_GROUP(af0, bf0)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af1, bf1)
+        ACX_GSTAMP(g1)
         __syncthreads();
+        ACX_GSTAMP(g2)
         ACX_READ_FRAGS(af0, bf0, abn, bbn, 0)
         __builtin_amdgcn_sched_barrier(0);
         ACX_MFMA_GROUP(af1, bf1)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af0, bf0)
         ACX_READ_FRAGS(af1, bf1, abn, bbn, 1)
+        ACX_GSTAMP(g3)
+#ifdef ACX_LAB_GEMM_STAMP
+        gs[0] += g1 - g0; gs[1] += g2 - g1; gs[2] += g3 - g2;
+#endif
     }
+#ifdef ACX_LAB_GEMM_STAMP
+    ACX_GSTAMP(gk1)
+#endif
     {
         const char* ab = As + ((nk - 1) & 1) * A_TILE + a_frag_off;
         const char* bb = Bs + ((nk - 1) & 1) * B_TILE + b_frag_off;
@@ -279,9 +331,14 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
 #undef ACX_DMA_TILE
 #undef ACX_READ_FRAGS
 #undef ACX_MFMA_GROUP
+#undef ACX_MFMA_GROUP_DMA
 #undef ACX_TOUCH
 
     // ---- epilogue: D tile layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) -----
+#ifdef ACX_LAB_GEMM_STAMP
+    unsigned long long ge0 = 0;
+    ACX_GSTAMP(ge0)
+#endif
 #ifdef ACX_LAB_NO_EPI      // diagnostic (tools/gemm_lab.hip): main loop only
     {
         float t = 0.f;
@@ -336,10 +393,26 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
             }
         }
     }
+#ifdef ACX_LAB_GEMM_STAMP
+    {
+        unsigned long long ge1 = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ACX_GSTAMP(ge1)
+        if (lane == 0) {
+            atomicAdd(&acx_gemm_stamps[0], gs[0]); atomicAdd(&acx_gemm_stamps[1], gs[1]); atomicAdd(&acx_gemm_stamps[2], gs[2]);
+            atomicAdd(&acx_gemm_stamps[3], gk1 - gk0); atomicAdd(&acx_gemm_stamps[4], ge1 - ge0);
+            atomicAdd(&acx_gemm_stamps[5], (unsigned long long)(nk - 1)); atomicAdd(&acx_gemm_stamps[6], 1ULL);
+            atomicAdd(&acx_gemm_stamps[7], ge0 - gk1);
+        }
+    }
+#endif
 }
 
+#ifndef ACX_LAB_EXTRA_LDS
+#define ACX_LAB_EXTRA_LDS 0
+#endif
 template <int BM, int BN>
-constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * kRowBytes; }
+constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * kRowBytes + ACX_LAB_EXTRA_LDS; }
 
 // ACX_GEMM_DW=1 builds the variant with a 5th, dedicated LDS-DMA wave.  Measured NEGATIVE on MI355X (tools/
 // gemm_lab: s2.pw1 657 vs 581 us, s2.pw2 742 vs 627 us): one wave cannot issue the 32 pieces of a tile and see

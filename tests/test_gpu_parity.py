@@ -242,3 +242,21 @@ def test_weight_reload_is_picked_up(synth_sd):
     ref.load_state_dict(synth_sd)
     c = ref.to("cuda").eval()(wav)["clipwise_logits"]
     assert torch.equal(b, c)
+
+
+def test_forward_is_graph_capturable(model):
+    """Nothing in the launch path allocates or synchronises (include/acx.h): the whole forward can be captured
+    into a hipGraph and replayed; replay == eager bit for bit."""
+    wav = synth.synth_waveforms(2, 32000, seed=9).cuda()
+    eager = model(wav)["clipwise_logits"].clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        model(wav)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            out = model(wav)["clipwise_logits"]
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)

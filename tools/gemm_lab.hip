@@ -51,6 +51,14 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
         double tf = 2.0 * s.M * s.N * s.K / (ms * 1e-3) / 1e12;
         printf("%-8s M=%-8lld N=%-5d K=%-5d  %8.1f us  %6.1f TF  (%4.1f%% of 157.3)\n", s.name, s.M, s.N, s.K, ms * 1e3, tf, 100 * tf / 157.3);
+#ifdef ACX_LAB_GEMM_STAMP
+        unsigned long long st[8];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(acx::acx_gemm_stamps), sizeof(st));
+        double nt = (double)st[5], nw = (double)st[6];
+        printf("   per k-tile cycles: g0-g2 (48 MFMA + DMA + reads) %.0f | barrier %.0f | g3 (16 MFMA + reads) %.0f  || per wave: main loop %.0f, last tile %.0f, epilogue %.0f (k-tiles/wave %.1f)\n",
+               st[0] / nt, st[1] / nt, st[2] / nt, st[3] / nw, st[7] / nw, st[4] / nw, nt / nw);
+        unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(acx::acx_gemm_stamps), z, sizeof(z));
+#endif
     }
     return 0;
 }
