@@ -76,6 +76,21 @@ def algorithmic_work(B, L):
     return work
 
 
+def measured_traffic():
+    """HBM bytes per launch per kernel class from the newest committed rocprofv3 PMC summary under profiles/
+    (tools/pmc_table.py: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes).  PMC counters cannot be read from
+    inside this process, so `traffic` is the profiled figure of the same workload, not a live measurement."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
+    if not files:
+        return {}, None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f)["classes"], os.path.basename(files[-1])
+    except Exception:
+        return {}, None
+
+
 def cpu_baseline(batch=8, reps=3):
     """Time the oracle on the host cores.  torch-CPU scales badly past a few dozen threads on this graph
     (and the box may expose more logical CPUs than it grants), so first probe a few thread counts on one
@@ -205,16 +220,21 @@ def main():
         per_launch_flops = work[dom][0] / kernels[dom]["launches_per_step"]
         avg_launch_s = kernels[dom]["ms_per_step"] * 1e-3 / kernels[dom]["launches_per_step"]
         ach = per_launch_flops / avg_launch_s / 1e12
+        traffic, traffic_src = measured_traffic()
+        tr = lambda k: (traffic.get(k, {}).get("hbm_traffic_bytes_per_launch") if B == 64 else None)
         line["roofline"] = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
-                            "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
-                            "avg_launch_ms": avg_launch_s * 1e3, "flops_per_launch": per_launch_flops}
+                            "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": tr(dom),
+                            "traffic_source": traffic_src, "avg_launch_ms": avg_launch_s * 1e3,
+                            "flops_per_launch": per_launch_flops,
+                            "algorithmic_bytes_per_launch": work[dom][1] / kernels[dom]["launches_per_step"]}
         mf = sum(work[k][0] for k in names) / sum(kernels[k]["ms_per_step"] * 1e-3 for k in names if k in kernels) / 1e12
         line["roofline_all_pointwise"] = {"bound": "mfma", "achieved": mf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                           "frac": mf / MFMA_F32_PEAK_TF}
         dw = kernels["dwconv"]
         line["roofline_dwconv"] = {"kernel": "dwconv7_kernel", "bound": "hbm", "achieved": dw["algorithmic_GBs"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dw["algorithmic_GBs"] / HBM_PEAK_GBS,
-                                   "traffic": None}
+                                   "traffic": tr("dwconv"), "traffic_source": traffic_src,
+                                   "algorithmic_bytes_per_launch": work["dwconv"][1] / dw["launches_per_step"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     if rank == 0:

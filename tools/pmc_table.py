@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Merge three rocprofv3 --pmc passes (SQ+GRBM | FETCH_SIZE | WRITE_SIZE) of tools/prof_step.py into one
+per-kernel table and a per-kernel-class traffic summary (HBM bytes per launch, FETCH_SIZE doubled as
+MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950).
+usage: pmc_table.py <dir_sq> <dir_fetch> <dir_write> <out_csv> <out_json>"""
+import collections, csv, glob, json, sys
+
+def load(d):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    out = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        e = out.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "grid": r["Grid_Size"],
+                                               "dt": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3})
+        e[r["Counter_Name"]] = float(r["Counter_Value"])
+    rows = list(out.values())
+    idx = [i for i, e in enumerate(rows) if "logmel" in e["name"]]
+    return rows[idx[-1]:]           # the last forward only
+
+def cls(name):
+    for key, c in (("logmel", "frontend"), ("stem_kernel", "stem"), ("dwconv7", "dwconv"), ("mlp_fused", "mlp_fused"),
+                   ("rowstats", "rowstats"), ("pool_head", "poolhead"), ("nhwc_to_nchw", "transpose")):
+        if key in name:
+            return c
+    if "gemm_f32_kernel" in name:
+        t = name.split("<")[1].split(">")[0].replace(" ", "").split(",")
+        return {"1": "pw1", "2": "pw2"}.get(t[4], "downsample")
+    return None
+
+sq, fe, wr = load(sys.argv[1]), load(sys.argv[2]), load(sys.argv[3])
+agg = collections.OrderedDict()
+with open(sys.argv[4], "w") as out:
+    out.write("# one forward, B=64 x 10 s, fp32 (tools/prof_step.py); three separate rocprofv3 --pmc passes.\n")
+    out.write("# fetch_MB_x2 = 2 * FETCH_SIZE (gfx950 reports half the bytes of 16 B/lane streaming reads); write_MB = WRITE_SIZE.\n")
+    out.write("class,kernel,grid,dur_us,clock_GHz,waves_per_SIMD,wait_any,wait_inst_any,valu_active,mfma_util,lds_bank_conflict_per_cu_cycle,fetch_MB_x2,write_MB\n")
+    for x, y, z in zip(sq, fe, wr):
+        c = cls(x["name"])
+        if c is None:
+            continue
+        gui = x["GRBM_GUI_ACTIVE"] / 8
+        fetch, write = 2 * y["FETCH_SIZE"] * 1024 / 1e6, z["WRITE_SIZE"] * 1024 / 1e6
+        mf = x.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024)
+        out.write('%s,"%s",%s,%.1f,%.2f,%.2f,%.3f,%.3f,%.3f,%.3f,%.3f,%.1f,%.1f\n' % (
+            c, x["name"][:70], x["grid"], x["dt"], gui / x["dt"] / 1e3, x["SQ_WAVE_CYCLES"] * 4 / (gui * 1024),
+            x["SQ_WAIT_ANY"] / x["SQ_WAVE_CYCLES"], x["SQ_WAIT_INST_ANY"] / x["SQ_WAVE_CYCLES"],
+            x["SQ_ACTIVE_INST_VALU"] / x["SQ_WAVE_CYCLES"], mf, x["SQ_LDS_BANK_CONFLICT"] / (gui * 256), fetch, write))
+        a = agg.setdefault(c, {"launches": 0, "fetch_MB_x2": 0.0, "write_MB": 0.0, "mfma_busy": 0.0, "simd_cycles": 0.0})
+        a["launches"] += 1; a["fetch_MB_x2"] += fetch; a["write_MB"] += write
+        a["mfma_busy"] += x.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0); a["simd_cycles"] += gui * 1024
+summary = {c: {"launches_per_step": a["launches"], "hbm_traffic_bytes_per_launch": (a["fetch_MB_x2"] + a["write_MB"]) * 1e6 / a["launches"],
+               "fetch_bytes_per_launch_x2": a["fetch_MB_x2"] * 1e6 / a["launches"], "write_bytes_per_launch": a["write_MB"] * 1e6 / a["launches"],
+               "mfma_util_cycles": a["mfma_busy"] / a["simd_cycles"]} for c, a in agg.items()}
+json.dump({"source": "rocprofv3 --pmc, 3 passes: SQ_*+GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE; FETCH_SIZE x2 (gfx950 correction)",
+           "workload": "one forward, B=64, 10 s @ 32 kHz, fp32", "classes": summary}, open(sys.argv[5], "w"), indent=1)
+print(json.dumps(summary, indent=1))
