@@ -101,6 +101,11 @@ struct acx_ctx {
     float* d_head_b = nullptr;    // [527]
 
     bool use_fused_mlp = true;    // ACX_DISABLE_FUSED_MLP=1 turns the fused stage-0/1 MLP kernel off
+    // two-way batch split over two HIP streams (fork/join by events): kernels of the two halves co-run, so
+    // an HBM-bound kernel of one half fills the matrix-pipe-bound phases of the other and vice versa
+    bool split_streams = true;    // ACX_SPLIT_STREAMS=0 turns it off
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     acx::Profile prof;
 };
 

@@ -356,6 +356,14 @@ int acx_create(int hip_device, acx_ctx** out) {
                  hip_device, prop.gcnArchName);
     acx_ctx* c = new acx_ctx();
     c->device = hip_device;
+    ACX_HIP(hipSetDevice(hip_device));
+    ACX_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    ACX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    ACX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    {
+        const char* e = std::getenv("ACX_SPLIT_STREAMS");
+        c->split_streams = !(e && e[0] == '0');
+    }
     *out = c;
     return ACX_OK;
 }
@@ -366,6 +374,9 @@ void acx_destroy(acx_ctx* c) {
     free_device(c);
     for (auto& r : c->prof.recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     delete c;
 }
 
@@ -409,27 +420,26 @@ int acx_stage_hw(int64_t L, int stage, int* H, int* Wd) {
     return ACX_OK;
 }
 
+// Batches of at least this many clips are split in two halves that run on two streams.
+static constexpr int kSplitMinBatch = 16;
+
 int acx_workspace_bytes(const acx_ctx* c, int B, int64_t L, int mode, size_t* out_bytes) {
     (void)c;
     if (!out_bytes || mode < 0 || mode > 2) ACX_FAIL(ACX_ERR_ARG, "acx_workspace_bytes: bad argument");
     Plan p;
     ACX_TRY(make_plan(B, L, &p));
     *out_bytes = p.total;
+    if (B >= kSplitMinBatch) {          // room for the two half-batch plans (whichever way the forward runs)
+        Plan p0, p1;
+        ACX_TRY(make_plan((B + 1) / 2, L, &p0));
+        ACX_TRY(make_plan(B / 2, L, &p1));
+        if (p0.total + p1.total > *out_bytes) *out_bytes = p0.total + p1.total;
+    }
     return ACX_OK;
 }
 
-int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float* out0, float* out1, void* workspace,
-                size_t workspace_bytes, void* stream) {
-    ACX_TRY(need_ready(c));
-    if (!wav || !out0 || !workspace) ACX_FAIL(ACX_ERR_ARG, "acx_forward: null pointer");
-    if (mode < 0 || mode > 2) ACX_FAIL(ACX_ERR_ARG, "acx_forward: bad mode %d", mode);
-    if (mode == ACX_MODE_LOGITS && !out1) ACX_FAIL(ACX_ERR_ARG, "acx_forward: logits mode needs out1 (probs)");
-    Plan p;
-    ACX_TRY(make_plan(B, L, &p));
-    if (workspace_bytes < p.total) ACX_FAIL(ACX_ERR_WORKSPACE, "workspace of %zu bytes is smaller than the %zu needed", workspace_bytes, p.total);
-    if (((uintptr_t)workspace & 255) != 0) ACX_FAIL(ACX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)workspace;
+static int forward_one(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float* out0, float* out1, char* ws,
+                       const Plan& p, hipStream_t st) {
     float* feat = (float*)(ws + p.off_feat);
     float* x[4];
     for (int s = 0; s < 4; ++s) x[s] = (float*)(ws + p.off_x[s]);
@@ -446,6 +456,42 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
     if (mode == ACX_MODE_FRAME) return launch_nhwc_to_nchw(c, x[3], out0, B, p.Hs[3], p.Ws[3], kDims[3], st);
     if (mode == ACX_MODE_SCENE) return launch_pool_head(c, x[3], B, p.Hs[3], out0, nullptr, nullptr, st);
     return launch_pool_head(c, x[3], B, p.Hs[3], nullptr, out0, out1, st);
+}
+
+int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float* out0, float* out1, void* workspace,
+                size_t workspace_bytes, void* stream) {
+    ACX_TRY(need_ready(c));
+    if (!wav || !out0 || !workspace) ACX_FAIL(ACX_ERR_ARG, "acx_forward: null pointer");
+    if (mode < 0 || mode > 2) ACX_FAIL(ACX_ERR_ARG, "acx_forward: bad mode %d", mode);
+    if (mode == ACX_MODE_LOGITS && !out1) ACX_FAIL(ACX_ERR_ARG, "acx_forward: logits mode needs out1 (probs)");
+    size_t need = 0;
+    ACX_TRY(acx_workspace_bytes(c, B, L, mode, &need));
+    if (workspace_bytes < need) ACX_FAIL(ACX_ERR_WORKSPACE, "workspace of %zu bytes is smaller than the %zu needed", workspace_bytes, need);
+    if (((uintptr_t)workspace & 255) != 0) ACX_FAIL(ACX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    // Clips are independent: a large batch runs as two halves on two streams (fork/join with events, so the call
+    // still looks like one unit of work on `stream` and stays graph-capturable).  Per-kernel event profiling
+    // runs un-split to keep launch durations clean.
+    if (c->split_streams && !c->prof.on && B >= kSplitMinBatch) {
+        const int B0 = (B + 1) / 2, B1 = B / 2;
+        Plan p0, p1;
+        ACX_TRY(make_plan(B0, L, &p0));
+        ACX_TRY(make_plan(B1, L, &p1));
+        const size_t per_clip0 = mode == ACX_MODE_FRAME ? (size_t)kDims[3] * p0.Hs[3] * p0.Ws[3]
+                                                        : (mode == ACX_MODE_SCENE ? (size_t)kDims[3] : (size_t)kClasses);
+        ACX_HIP(hipEventRecord(c->ev_fork, st));
+        ACX_HIP(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        ACX_TRY(forward_one(c, wav, B0, L, mode, out0, out1, ws, p0, st));
+        ACX_TRY(forward_one(c, wav + (size_t)B0 * L, B1, L, mode, out0 + B0 * per_clip0, out1 ? out1 + B0 * per_clip0 : nullptr,
+                            ws + p0.total, p1, c->aux_stream));
+        ACX_HIP(hipEventRecord(c->ev_join, c->aux_stream));
+        ACX_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+        return ACX_OK;
+    }
+    Plan p;
+    ACX_TRY(make_plan(B, L, &p));
+    return forward_one(c, wav, B, L, mode, out0, out1, ws, p, st);
 }
 
 int acx_logmel_bn0(acx_ctx* c, const float* wav, int B, int64_t L, float* out, int apply_bn0, void* stream) {

@@ -249,6 +249,7 @@ def test_forward_is_graph_capturable(model):
     into a hipGraph and replayed; replay == eager bit for bit."""
     wav = synth.synth_waveforms(2, 32000, seed=9).cuda()
     eager = model(wav)["clipwise_logits"].clone()
+    torch.cuda.synchronize()          # the side stream below shares the model's workspace with this eager call
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
@@ -256,7 +257,32 @@ def test_forward_is_graph_capturable(model):
         torch.cuda.synchronize()
         with torch.cuda.graph(g, stream=s):
             out = model(wav)["clipwise_logits"]
+    torch.cuda.synchronize()
     out.zero_()
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+def test_split_batch_is_graph_capturable_and_exact(model):
+    """B >= 16 runs as two halves on two streams inside acx_forward (event fork/join): still one capturable unit,
+    and every clip equals the un-split result bit for bit."""
+    wav = synth.synth_waveforms(17, 16000, seed=10).cuda()          # odd split 9 + 8
+    whole = model(wav)
+    parts = torch.cat([model(wav[:9])["clipwise_logits"], model(wav[9:])["clipwise_logits"]])
+    assert torch.equal(whole["clipwise_logits"], parts)
+    fr = model.forward_frame_embeddings(wav)
+    assert torch.equal(fr[10], model.forward_frame_embeddings(wav[10:11])[0])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        model(wav)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            out = model(wav)["clipwise_logits"]
+    torch.cuda.synchronize()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, parts)
