@@ -65,10 +65,16 @@ ACX_HD int fft512_pass(cf* v, int j, int Ns, const cf* tw1024) {
     return (j / Ns) * Ns * 8 + k;
 }
 
-// Bin k (0..512) of the 1024-point real FFT from the 512-point FFT Z of the packed signal.
+// Padded index of complex element i in the LDS exchange buffers: one pad slot every 8 elements.  Turns the
+// 8- and 16-way bank conflicts of the radix-8 scatter (strides of 64 B and 512 B) into conflict-free
+// (72-B / 576-B strides); the buffers hold 512 + 64 slots.
+ACX_HD int fft_pad(int i) { return i + (i >> 3); }
+constexpr int kFftBufSlots = 576;
+
+// Bin k (0..512) of the 1024-point real FFT from the 512-point FFT Z of the packed signal (Z padded).
 ACX_HD cf rfft1024_bin(const cf* Z, int k, const cf* tw1024) {
-    cf a = Z[k & 511];
-    cf b = Z[(512 - k) & 511];
+    cf a = Z[fft_pad(k & 511)];
+    cf b = Z[fft_pad((512 - k) & 511)];
     b.y = -b.y;                                   // conj
     cf e = cf_make(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
     cf d = cf_make(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));

@@ -16,7 +16,7 @@ constexpr int kFrontWaves = 4;
 
 struct FrontLds {
     cf tw[1024];
-    cf buf[kFrontWaves][2][512];
+    cf buf[kFrontWaves][2][kFftBufSlots];
     float P[kFrontWaves][520];
 };
 
@@ -86,19 +86,19 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         cf* bufB = lds.buf[wave][1];
         int dst = fft512_pass(v, lane, 1, lds.tw);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) bufA[dst + r] = v[r];
+        for (int r = 0; r < 8; ++r) bufA[fft_pad(dst + r)] = v[r];
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = bufA[lane + 64 * r];
+        for (int r = 0; r < 8; ++r) v[r] = bufA[fft_pad(lane + 64 * r)];
         dst = fft512_pass(v, lane, 8, lds.tw);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) bufB[dst + r * 8] = v[r];
+        for (int r = 0; r < 8; ++r) bufB[fft_pad(dst + r * 8)] = v[r];
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = bufB[lane + 64 * r];
+        for (int r = 0; r < 8; ++r) v[r] = bufB[fft_pad(lane + 64 * r)];
         dst = fft512_pass(v, lane, 64, lds.tw);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) bufA[dst + r * 64] = v[r];
+        for (int r = 0; r < 8; ++r) bufA[fft_pad(dst + r * 64)] = v[r];
         __syncthreads();
         // power spectrum, 513 bins
         float* P = lds.P[wave];
