@@ -379,8 +379,10 @@ static int launch_dw_cfg(const BlockW& w, int C, const float* x, float* y, int B
     }
     const int tiles_w = W / TW, tiles_h = (H + TH - 1) / TH;
     const long long columns = (long long)B * tiles_w * (C / kDwSlice);
-    // enough workgroups for ~4 rounds on 256 CUs x 2 resident, but segments of at least 2 row tiles
-    int n_seg = (int)((2048 + columns - 1) / columns);
+    // Workgroups = columns x row segments.  Two workgroups are resident per CU (512 slots): aim at a whole
+    // number of rounds (3 x 512) -- a fractional last round idles half the chip for a whole workgroup life
+    // (measured 4.5 rounds = 5) -- with segments of at least 2 row tiles to amortise the ring prologue.
+    int n_seg = (int)((1536 + columns / 2) / columns);
     if (n_seg > tiles_h / 2) n_seg = tiles_h / 2;
     if (n_seg < 1) n_seg = 1;
     const long long blocks = columns * n_seg;
