@@ -28,6 +28,7 @@ SIGNATURES = {
     "acx_destroy": (None, [_vp]),
     "acx_set_weight": (_c_int, [_vp, ctypes.c_char_p, _vp, ctypes.POINTER(_c_i64), _c_int]),
     "acx_finalize": (_c_int, [_vp]),
+    "acx_set_precision": (_c_int, [_vp, _c_int]),
     "acx_num_frames": (_c_int, [_c_i64, _pint]),
     "acx_stage_hw": (_c_int, [_c_i64, _c_int, _pint, _pint]),
     "acx_workspace_bytes": (_c_int, [_vp, _c_int, _c_i64, _c_int, ctypes.POINTER(_c_sz)]),
@@ -90,6 +91,9 @@ def stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+PRECISIONS = {"fp32": 0, "bf16": 1}
+
+
 class Context:
     """Owns one acx_ctx (repacked weights on one GPU)."""
 
@@ -108,6 +112,11 @@ class Context:
     @property
     def handle(self):
         return self._h
+
+    def set_precision(self, precision):
+        """"fp32" (default, the parity path) or "bf16" (bf16 MFMA operands, fp32 accumulate / LayerNorm / residual).
+        Takes effect at the next load_state_dict()."""
+        check(lib().acx_set_precision(self._h, PRECISIONS[precision]))
 
     def load_state_dict(self, sd):
         """sd: mapping key -> tensor (any device); fp32 tensors are staged through host memory."""

@@ -56,11 +56,14 @@ struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layou
     float* w2 = nullptr;     // [C][4C]   gamma * pwconv2
     float* b2 = nullptr;     // [C]       gamma * pwconv2 bias
     float* wpack = nullptr;  // [4C/32][64*C]  per hidden chunk: w1 rows [32][C] then w2 columns [C][32] (fused MLP)
+    uint16_t* w1h = nullptr; // bf16 mode: [4C][Cp]  folded pwconv1 rounded to bf16, K zero-padded to Cp = pad64(C)
+    uint16_t* w2h = nullptr; // bf16 mode: [C][4C]   gamma * pwconv2 rounded to bf16
 };
 
 struct DownW {           // downsample_layers[i], i>=1 (convnext.py:230-235)
     float* w = nullptr;      // [C'][4C]  k = (dy*2+dx)*C + c, LayerNorm weight folded in
     float* b = nullptr;      // [C']      bias + W . ln_bias
+    uint16_t* wh = nullptr;  // bf16 mode: [C'][4*Cp]  k = (dy*2+dx)*Cp + c
 };
 
 struct Profile {
@@ -100,6 +103,7 @@ struct acx_ctx {
     float* d_head_w = nullptr;    // [527][768]
     float* d_head_b = nullptr;    // [527]
 
+    int precision = ACX_PREC_F32; // acx_set_precision: ACX_PREC_BF16 runs the dense contractions on bf16 MFMA
     bool use_fused_mlp = true;    // ACX_DISABLE_FUSED_MLP=1 turns the fused stage-0/1 MLP kernel off
     // two-way batch split over two HIP streams (fork/join by events): kernels of the two halves co-run, so
     // an HBM-bound kernel of one half fills the matrix-pipe-bound phases of the other and vice versa
@@ -140,6 +144,16 @@ struct GemmArgs {
     int epi; int cls;
 };
 int launch_gemm(acx_ctx* c, const GemmArgs& a, hipStream_t s);
+// bf16-precision variants (gemm_bf16.hip): A, Wt bf16; EPI_GELU writes bf16, the others fp32
+inline int pad64(int v) { return (v + 63) / 64 * 64; }
+int launch_layernorm_rows_bf16(acx_ctx* c, const float* x, void* out, int64_t M, int C, hipStream_t s);
+struct GemmBf16Args {
+    const void* A; const void* Wt; const float* bias; void* out; const float* resid;
+    int64_t M; int N; int Kp; int lda;
+    int gather; int H, W, Cp, Ho, Wo;
+    int epi; int cls;
+};
+int launch_gemm_bf16(acx_ctx* c, const GemmBf16Args& a, hipStream_t s);
 bool mlp_fused_supported(int C);
 // x += MLP(LN(y)) for one block, hidden activation kept in registers (mlp_fused.hip)
 int launch_mlp_fused(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s);

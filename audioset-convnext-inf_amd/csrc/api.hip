@@ -91,6 +91,23 @@ static int upload(acx_ctx* c, const std::vector<T>& h, T** out) {
     return ACX_OK;
 }
 
+static uint16_t to_bf16(float f) {      // round to nearest even, as v_cvt_pk_bf16_f32 does
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// rows x K fp32 -> rows x Kp bf16, source column k of group q (K = groups * Kg) lands at q * Kgp + k
+static std::vector<uint16_t> bf16_rows(const std::vector<float>& w, int rows, int groups, int Kg, int Kgp) {
+    std::vector<uint16_t> h((size_t)rows * groups * Kgp, 0);
+    for (int n = 0; n < rows; ++n)
+        for (int q = 0; q < groups; ++q)
+            for (int k = 0; k < Kg; ++k)
+                h[((size_t)n * groups + q) * Kgp + k] = to_bf16(w[((size_t)n * groups + q) * Kg + k]);
+    return h;
+}
+
 static void free_device(acx_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
@@ -200,6 +217,8 @@ static int finalize_impl(acx_ctx* c) {
         }
         ACX_TRY(upload(c, w, &c->down[i].w));
         ACX_TRY(upload(c, b, &c->down[i].b));
+        c->down[i].wh = nullptr;
+        if (c->precision == ACX_PREC_BF16) ACX_TRY(upload(c, bf16_rows(w, Co, 4, Ci, pad64(Ci)), &c->down[i].wh));
     }
     // ---- blocks -----------------------------------------------------------------------------
     for (int s = 0; s < 4; ++s) {
@@ -238,6 +257,10 @@ static int finalize_impl(acx_ctx* c) {
             }
             ACX_TRY(upload(c, f2, &bw.w2));
             ACX_TRY(upload(c, fb2, &bw.b2));
+            if (c->precision == ACX_PREC_BF16) {
+                ACX_TRY(upload(c, bf16_rows(f1, 4 * C, 1, C, pad64(C)), &bw.w1h));
+                ACX_TRY(upload(c, bf16_rows(f2, C, 1, 4 * C, 4 * C), &bw.w2h));
+            }
             if (mlp_fused_supported(C)) {       // chunk-major image for the fused kernel's LDS-DMA
                 const int nch = 4 * C / 32;
                 std::vector<float> pk((size_t)nch * 64 * C);
@@ -291,11 +314,33 @@ static int make_plan(int B, int64_t L, Plan* p) {
     return ACX_OK;
 }
 
+// bf16 precision: y -> fp32 LayerNorm -> bf16 rows; pwconv1 + GELU -> bf16 hidden; pwconv2 + residual -> fp32 x.
+// Both bf16 arrays live in the `hidden` scratch (sized for the fp32 hidden activation): [M][4C] then [M][Cp].
+static int run_mlp_bf16(acx_ctx* c, const BlockW& bw, int C, const float* y, float* x, float* hidden, int64_t M,
+                        hipStream_t st) {
+    const int Cp = pad64(C);
+    char* hb = reinterpret_cast<char*>(hidden);
+    char* yb = hb + align_up((size_t)M * 4 * C * 2);
+    ACX_TRY(launch_layernorm_rows_bf16(c, y, yb, M, C, st));
+    GemmBf16Args g1{};
+    g1.A = yb; g1.Wt = bw.w1h; g1.bias = bw.b1; g1.out = hb; g1.M = M; g1.N = 4 * C; g1.Kp = Cp; g1.lda = Cp;
+    g1.epi = EPI_GELU; g1.cls = ACX_K_PW1;
+    ACX_TRY(launch_gemm_bf16(c, g1, st));
+    GemmBf16Args g2{};
+    g2.A = hb; g2.Wt = bw.w2h; g2.bias = bw.b2; g2.out = x; g2.resid = x; g2.M = M; g2.N = C; g2.Kp = 4 * C; g2.lda = 4 * C;
+    g2.epi = EPI_RESID; g2.cls = ACX_K_PW2;
+    return launch_gemm_bf16(c, g2, st);
+}
+
 static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden, float* stats, int B, int H, int Wd,
                      hipStream_t st) {
     const int C = kDims[s];
     const BlockW& bw = c->blocks[s][j];
     const int64_t M = (int64_t)B * H * Wd;
+    if (c->precision == ACX_PREC_BF16) {
+        ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
+        return run_mlp_bf16(c, bw, C, y, x, hidden, M, st);
+    }
     if (c->use_fused_mlp && mlp_fused_supported(C)) {
         ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));      // LN statistics are computed in-kernel
         return launch_mlp_fused(c, bw, C, y, x, M, st);
@@ -315,6 +360,15 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
 static int run_downsample(acx_ctx* c, int i, const float* x, float* out, float* xnorm, int B, int H, int Wd,
                           hipStream_t st) {
     const int Ci = kDims[i - 1], Co = kDims[i];
+    if (c->precision == ACX_PREC_BF16) {
+        const int Cp = pad64(Ci);
+        ACX_TRY(launch_layernorm_rows_bf16(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
+        GemmBf16Args g{};
+        g.A = xnorm; g.Wt = c->down[i].wh; g.bias = c->down[i].b; g.out = out;
+        g.gather = 1; g.H = H; g.W = Wd; g.Cp = Cp; g.Ho = H / 2; g.Wo = Wd / 2;
+        g.M = (int64_t)B * g.Ho * g.Wo; g.N = Co; g.Kp = 4 * Cp; g.lda = Cp; g.epi = EPI_BIAS; g.cls = ACX_K_DOWNSAMPLE;
+        return launch_gemm_bf16(c, g, st);
+    }
     ACX_TRY(launch_layernorm_rows(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
     GemmArgs g{};
     g.A = xnorm; g.Wt = c->down[i].w; g.bias = c->down[i].b; g.out = out;
@@ -404,6 +458,13 @@ int acx_finalize(acx_ctx* c) {
     int rc = finalize_impl(c);
     if (rc != ACX_OK) { free_device(c); }
     return rc;
+}
+
+int acx_set_precision(acx_ctx* c, int precision) {
+    if (!c) ACX_FAIL(ACX_ERR_ARG, "null context");
+    if (precision != ACX_PREC_F32 && precision != ACX_PREC_BF16) ACX_FAIL(ACX_ERR_ARG, "acx_set_precision: unknown precision %d", precision);
+    if (precision != c->precision) { c->precision = precision; c->finalized = false; }
+    return ACX_OK;
 }
 
 int acx_num_frames(int64_t L, int* T) {
@@ -523,6 +584,7 @@ int acx_block_mlp(acx_ctx* c, int stage, int block, const float* y, const float*
     const int C = kDims[stage];
     const BlockW& bw = c->blocks[stage][block];
     const int64_t M = (int64_t)B * H * Wd;
+    if (c->precision == ACX_PREC_BF16) return run_mlp_bf16(c, bw, C, y, x, hidden, M, (hipStream_t)stream);
     if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused(c, bw, C, y, x, M, (hipStream_t)stream);
     GemmArgs g1{};
     g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.colsum = bw.w1sum; g1.M = M; g1.N = 4 * C; g1.K = C;

@@ -295,8 +295,11 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
 // Per-row LayerNorm statistics over C channels (biased variance, eps inside the sqrt --
 // convnext.py:537-540 / F.layer_norm): stats[row] = (mean, rstd).  G = C/12 lanes per row, each
 // lane holds 3 float4; reductions are xor-shuffles inside the G-lane group (G = 8..64).
-// NORMALIZE: write (x - mean) * rstd instead (input of the downsample convs, convnext.py:230-235).
-template <int G, bool NORMALIZE>
+// NORMALIZE 1: write (x - mean) * rstd instead (input of the downsample convs, convnext.py:230-235).
+// NORMALIZE 2: the same rounded to bf16, rows padded with zeros to a multiple of 64 channels (A operand of the
+// bf16-precision GEMMs, gemm_bf16.hip); the statistics and the normalisation itself stay fp32.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <int G, int NORMALIZE>
 __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                        long long rows, float eps) {
     constexpr int C = G * 12;
@@ -328,7 +331,23 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__
 #pragma unroll
         for (int o = G / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
         const float rstd = 1.0f / sqrtf(d * (1.0f / C) + eps);
-        if (NORMALIZE) {      // `stats` is the (rows, C) output: (x - mean) * rstd, affine folded downstream
+        if (NORMALIZE == 2) {
+            if (valid) {
+                constexpr int Cp = (C + 63) / 64 * 64;
+                __bf16* o = reinterpret_cast<__bf16*>(stats) + row * Cp;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    bf16x4 q;
+                    q[0] = (__bf16)((v[k].x - mean) * rstd); q[1] = (__bf16)((v[k].y - mean) * rstd);
+                    q[2] = (__bf16)((v[k].z - mean) * rstd); q[3] = (__bf16)((v[k].w - mean) * rstd);
+                    *reinterpret_cast<bf16x4*>(o + 4 * (g + G * k)) = q;
+                }
+                if (Cp > C && 4 * g < Cp - C) {
+                    bf16x4 z; z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
+                    *reinterpret_cast<bf16x4*>(o + C + 4 * g) = z;
+                }
+            }
+        } else if (NORMALIZE == 1) {      // `stats` is the (rows, C) output: (x - mean) * rstd, affine folded downstream
             if (valid) {
                 float4* o = reinterpret_cast<float4*>(stats + row * C);
 #pragma unroll
@@ -342,7 +361,7 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__
     }
 }
 
-template <bool NORMALIZE>
+template <int NORMALIZE>
 static int launch_rows(acx_ctx* c, const float* x, float* out, int64_t M, int C, hipStream_t s) {
     const int G = C / 12;
     long long blocks = (M + (256 / G) - 1) / (256 / G);
@@ -361,11 +380,15 @@ static int launch_rows(acx_ctx* c, const float* x, float* out, int64_t M, int C,
 }
 
 int launch_rowstats(acx_ctx* c, const float* x, float* stats, int64_t M, int C, hipStream_t s) {
-    return launch_rows<false>(c, x, stats, M, C, s);
+    return launch_rows<0>(c, x, stats, M, C, s);
 }
 
 int launch_layernorm_rows(acx_ctx* c, const float* x, float* out, int64_t M, int C, hipStream_t s) {
-    return launch_rows<true>(c, x, out, M, C, s);
+    return launch_rows<1>(c, x, out, M, C, s);
+}
+
+int launch_layernorm_rows_bf16(acx_ctx* c, const float* x, void* out, int64_t M, int C, hipStream_t s) {
+    return launch_rows<2>(c, x, reinterpret_cast<float*>(out), M, C, s);
 }
 
 template <int TW, int TH>

@@ -1,0 +1,275 @@
+// bf16 precision mode (BASELINE configs[2]: "bf16 with fp32 LayerNorm"): the dense contractions on
+// v_mfma_f32_32x32x16_bf16 -- bf16 operands, fp32 accumulate -- everything else (residual stream, LayerNorm
+// statistics, depthwise conv, frontend, head) stays fp32.
+//   A operands are bf16 in HBM: the fp32 LayerNorm pass writes its normalised rows as bf16 (ln_rows_bf16 in
+//   dwconv.hip), pwconv1's epilogue writes the hidden activation as bf16.  Weights are rounded to bf16 once
+//   at acx_finalize (K padded to a multiple of 64).
+// Same structure as gemm.hip: 128 x BN tiles, 128-B LDS rows (= 64 bf16 of K), both operands by LDS-DMA with
+// the XOR swizzle on the source address, fragments double-buffered in registers, one barrier per k-tile.  A
+// fragment read is still one ds_read_b128: lane half h takes chunk 2g+h of its row = k 16g+8h .. +7, exactly
+// the A/B lane map of the 32x32x16 instruction, so one MFMA per (tile, k-group) replaces four fp32 ones.
+#include "acx_internal.h"
+
+namespace acx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kBfRowBytes = 128;        // 64 bf16 per LDS row
+constexpr int kBfBK = 64;
+
+__device__ __forceinline__ float gelu_erf_b(float v) {     // see gemm.hip
+    const float av = fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678f, av, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(v * v * -0.72134752f);
+    const float q = pl * t * e;
+    return fmaf(-0.5f * av, q, fmaxf(v, 0.0f));
+}
+
+struct GemmBfParams {
+    const __bf16* A; const __bf16* Wt; const float* bias; void* out; const float* resid;
+    long long M; int N; int Kp; int lda;      // Kp: padded K (multiple of 64) = row stride of Wt; lda: row stride of A
+    int H, W, Cp, Ho, Wo;                     // gather mode: A is (B,H,W,Cp) bf16, row m = (b,ho,wo), k = (dy*2+dx)*Cp + c
+    int tiles_n;
+};
+
+__device__ __forceinline__ void lds_dma16_b(const __bf16* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// EPI: 0 bias -> fp32, 1 bias + GELU -> bf16, 2 bias + residual -> fp32
+template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
+    constexpr int TM = kBM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr int A_TILE = kBM * kBfRowBytes, B_TILE = BN * kBfRowBytes;
+    constexpr int A_DMA = kBM / 32, B_DMA = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + 2 * A_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    long long lid = blockIdx.x;
+    {
+        const long long nwg = gridDim.x, per = (nwg + 7) >> 3, full = nwg - (per - 1) * 8;
+        const long long xcd = lid & 7, k = lid >> 3;
+        lid = (xcd < full ? xcd * per : full * per + (xcd - full) * (per - 1)) + k;
+    }
+    const int tile_n = (int)(lid % p.tiles_n);
+    const long long tile_m = lid / p.tiles_n;
+    const long long m0 = tile_m * kBM;
+    const int n0 = tile_n * BN;
+
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const __bf16* a_src[A_DMA];
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i) {
+        const int row = A_DMA * 8 * wave + 8 * i + prow;
+        const int chunk = pchunk ^ ((row >> 1) & 7);
+        long long m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        if (GATHER) {
+            const int wo = (int)(m % p.Wo);
+            const long long t = m / p.Wo;
+            const int ho = (int)(t % p.Ho);
+            const long long b = t / p.Ho;
+            a_src[i] = p.A + ((b * p.H + 2 * ho) * p.W + 2 * wo) * p.Cp + 8 * chunk;
+        } else {
+            a_src[i] = p.A + m * p.lda + 8 * chunk;
+        }
+    }
+    const __bf16* b_src[B_DMA];
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i) {
+        const int row = B_DMA * 8 * wave + 8 * i + prow;
+        const int chunk = pchunk ^ ((row >> 1) & 7);
+        b_src[i] = p.Wt + (long long)(n0 + row) * p.Kp + 8 * chunk;
+    }
+    char* a_dst = As + A_DMA * 8 * wave * kBfRowBytes;
+    char* b_dst = Bs + B_DMA * 8 * wave * kBfRowBytes;
+#define ACX_DMA_TILE(k0, buf)                                                                          \
+    {                                                                                                  \
+        long long koff = (k0);                                                                         \
+        if (GATHER) {                                                                                  \
+            const int qd = (k0) / p.Cp;                                                                \
+            koff = (long long)((qd >> 1) * p.W + (qd & 1)) * p.Cp + ((k0) - qd * p.Cp);                \
+        }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < A_DMA; ++i)                                              \
+            lds_dma16_b(a_src[i] + koff, a_dst + (buf) * A_TILE + i * 8 * kBfRowBytes);                \
+        _Pragma("unroll") for (int i = 0; i < B_DMA; ++i)                                              \
+            lds_dma16_b(b_src[i] + (k0), b_dst + (buf) * B_TILE + i * 8 * kBfRowBytes);                \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sw = (l31 >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) foff[g] = l31 * kBfRowBytes + (((2 * g + hh) ^ sw) << 4);
+    const int a_frag_off = wm * TM * 32 * kBfRowBytes;
+    const int b_frag_off = wn * TN * 32 * kBfRowBytes;
+#define ACX_READ_FRAGS(af_, bf_, abase, bbase, g)                                                      \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+            af_[i] = *reinterpret_cast<const f32x4*>((abase) + i * 32 * kBfRowBytes + foff[g]);        \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+            bf_[j] = *reinterpret_cast<const f32x4*>((bbase) + j * 32 * kBfRowBytes + foff[g]);        \
+    }
+#define ACX_MFMA_GROUP(af_, bf_)                                                                       \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af_[i]),    \
+                                                                __builtin_bit_cast(bf16x8, bf_[j]), acc[i][j], 0, 0, 0); \
+    }
+#define ACX_TOUCH(af_, bf_)   /* see gemm.hip: hipcc only emits lgkmcnt(0) next to an LDS-DMA */      \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af_[i]));                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bf_[j]));                \
+    }
+
+    const int nk = p.Kp / kBfBK;
+    ACX_DMA_TILE(0, 0);
+    __syncthreads();
+    f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+    {
+        const char* ab = As + a_frag_off;
+        const char* bb = Bs + b_frag_off;
+        ACX_READ_FRAGS(af0, bf0, ab, bb, 0)
+        ACX_READ_FRAGS(af1, bf1, ab, bb, 1)
+    }
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const char* ab = As + (kt & 1) * A_TILE + a_frag_off;
+        const char* bb = Bs + (kt & 1) * B_TILE + b_frag_off;
+        const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
+        const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
+        ACX_DMA_TILE((kt + 1) * kBfBK, (kt + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af0, bf0)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(af1, bf1)
+        ACX_READ_FRAGS(af0, bf0, ab, bb, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af1, bf1)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(af0, bf0)
+        ACX_READ_FRAGS(af1, bf1, ab, bb, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af0, bf0)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(af1, bf1)
+        __syncthreads();
+        ACX_READ_FRAGS(af0, bf0, abn, bbn, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af1, bf1)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(af0, bf0)
+        ACX_READ_FRAGS(af1, bf1, abn, bbn, 1)
+    }
+    {
+        const char* ab = As + ((nk - 1) & 1) * A_TILE + a_frag_off;
+        const char* bb = Bs + ((nk - 1) & 1) * B_TILE + b_frag_off;
+        ACX_MFMA_GROUP(af0, bf0)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_READ_FRAGS(af0, bf0, ab, bb, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af1, bf1)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_READ_FRAGS(af1, bf1, ab, bb, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_GROUP(af0, bf0)
+        ACX_MFMA_GROUP(af1, bf1)
+    }
+#undef ACX_DMA_TILE
+#undef ACX_READ_FRAGS
+#undef ACX_MFMA_GROUP
+#undef ACX_TOUCH
+
+    // ---- epilogue: D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ---------------------
+    const bool full = m0 + kBM <= p.M;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const long long mb = m0 + (wm * TM + i) * 32 + 4 * hh;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + l31;
+            const float bn = p.bias[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                if (full || mb + dr < p.M) {
+                    const long long off = (mb + dr) * p.N + n;
+                    float v = acc[i][j][r] + bn;
+                    if (EPI == 1) {
+                        reinterpret_cast<__bf16*>(p.out)[off] = (__bf16)gelu_erf_b(v);
+                    } else {
+                        if (EPI == 2) v += p.resid[off];
+                        reinterpret_cast<float*>(p.out)[off] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
+static int launch_bf_cfg(const GemmBfParams& p0, hipStream_t s) {
+    GemmBfParams p = p0;
+    p.tiles_n = p.N / BN;
+    const long long tiles_m = (p.M + kBM - 1) / kBM;
+    const long long blocks = tiles_m * p.tiles_n;
+    if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm_bf16: grid too large");
+    constexpr size_t lds = (size_t)2 * (kBM + BN) * kBfRowBytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(p);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
+template <int EPI, int GATHER>
+static int launch_bf_bn(const GemmBfParams& p, hipStream_t s) {
+    if (p.N % 128 == 0) return launch_bf_cfg<128, 128, 2, 2, EPI, GATHER>(p, s);
+    if (p.N % 96 == 0) return launch_bf_cfg<128, 96, 4, 1, EPI, GATHER>(p, s);
+    ACX_FAIL(ACX_ERR_SHAPE, "gemm_bf16: N=%d is not a multiple of 96 or 128", p.N);
+}
+
+int launch_gemm_bf16(acx_ctx* c, const GemmBf16Args& a, hipStream_t s) {
+    if (a.Kp % kBfBK != 0) ACX_FAIL(ACX_ERR_SHAPE, "gemm_bf16: padded K=%d is not a multiple of %d", a.Kp, kBfBK);
+    if (a.M <= 0) return ACX_OK;
+    GemmBfParams p;
+    p.A = reinterpret_cast<const __bf16*>(a.A); p.Wt = reinterpret_cast<const __bf16*>(a.Wt); p.bias = a.bias;
+    p.out = a.out; p.resid = a.resid; p.M = a.M; p.N = a.N; p.Kp = a.Kp; p.lda = a.lda;
+    p.H = a.H; p.W = a.W; p.Cp = a.Cp; p.Ho = a.Ho; p.Wo = a.Wo; p.tiles_n = 0;
+    ProfScope ps(c, a.cls, s);
+    if (a.gather) {
+        if (a.epi != EPI_BIAS || a.Cp % kBfBK != 0) ACX_FAIL(ACX_ERR_ARG, "gemm_bf16: bad gather configuration");
+        return launch_bf_bn<0, 1>(p, s);
+    }
+    if (a.epi == EPI_GELU) return launch_bf_bn<1, 0>(p, s);
+    if (a.epi == EPI_RESID) return launch_bf_bn<2, 0>(p, s);
+    if (a.epi == EPI_BIAS) return launch_bf_bn<0, 0>(p, s);
+    ACX_FAIL(ACX_ERR_ARG, "gemm_bf16: unknown epilogue %d", a.epi);
+}
+
+}  // namespace acx

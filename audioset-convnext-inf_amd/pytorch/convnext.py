@@ -128,6 +128,7 @@ class ConvNeXt(nn.Module):
         self.head_audioset.bias.data.mul_(head_init_scale)
 
         self._ctx = {}          # device index -> (_ffi.Context, weight signature)
+        self.precision = "fp32" # set_precision("bf16"): bf16 MFMA contractions (BASELINE configs[2])
         self._ws = {}           # device index -> workspace tensor
 
     def _init_weights(self, m):
@@ -137,7 +138,16 @@ class ConvNeXt(nn.Module):
 
     # ------------------------------------------------------------------------------ native side
     def _signature(self):
-        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        return (self.precision,) + tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+
+    def set_precision(self, precision):
+        """"fp32": the reference's arithmetic (default; 1e-3 parity).  "bf16": pointwise / downsample contractions
+        with bf16 operands and fp32 accumulation; LayerNorm, residual stream, depthwise conv, frontend and head
+        stay fp32.  The reference has no such switch (closest: torch autocast around its nn.Linear layers)."""
+        if precision not in _ffi.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_ffi.PRECISIONS))
+        self.precision = precision
+        return self
 
     def native_context(self, device):
         """The libacx context holding this module's weights on `device` (rebuilt when they change)."""
@@ -147,6 +157,7 @@ class ConvNeXt(nn.Module):
         if hit is not None and hit[1] == sig:
             return hit[0]
         ctx = hit[0] if hit is not None else _ffi.Context(idx)
+        ctx.set_precision(self.precision)
         ctx.load_state_dict(self.state_dict())
         self._ctx[idx] = (ctx, sig)
         return ctx

@@ -35,15 +35,17 @@ from audioset_convnext_inf_amd.pytorch.convnext import convnext_tiny   # noqa: E
 CLIP_SAMPLES = 320000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured-achievable)
 MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA, dense (no xf32 on gfx950)
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
 DIMS, DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
 
 
 FUSED_STAGES = (0, 1) if os.environ.get("ACX_DISABLE_FUSED_MLP", "0") != "1" else ()
 
 
-def algorithmic_work(B, L):
+def algorithmic_work(B, L, precision="fp32"):
     """Per kernel class: (total FLOPs, total algorithmic HBM bytes) of ONE forward.
-    Stages 0-1 run the fused MLP kernel (hidden activation stays on chip), stages 2-3 the two GEMMs."""
+    fp32: stages 0-1 run the fused MLP kernel (hidden activation stays on chip), stages 2-3 the two GEMMs.
+    bf16: every block is LN->bf16 rows (counted under rowstats), pwconv1 (bf16 in, bf16 hidden out), pwconv2."""
     T = L // 320 + 1
     hs = [(T + 4) // 4 + 1]
     ws = [56]
@@ -59,7 +61,14 @@ def algorithmic_work(B, L):
         n = DEPTHS[s]
         work["dwconv"][0] += n * 2.0 * 49 * pix[s] * C
         work["dwconv"][1] += n * 2.0 * pix[s] * C * 4                      # read x, write y
-        if s in FUSED_STAGES:
+        if precision == "bf16":
+            Cp = (C + 63) // 64 * 64
+            work["rowstats"][1] += n * (pix[s] * C * 4 + pix[s] * Cp * 2)
+            work["pw1"][0] += n * 2.0 * pix[s] * C * 4 * C
+            work["pw1"][1] += n * (pix[s] * Cp * 2 + pix[s] * 4 * C * 2)
+            work["pw2"][0] += n * 2.0 * pix[s] * C * 4 * C
+            work["pw2"][1] += n * (pix[s] * 4 * C * 2 + 2.0 * pix[s] * C * 4)
+        elif s in FUSED_STAGES:
             work["mlp_fused"][0] += n * 4.0 * pix[s] * C * 4 * C
             work["mlp_fused"][1] += n * 3.0 * pix[s] * C * 4                   # y in, x in, x out
         else:
@@ -70,8 +79,9 @@ def algorithmic_work(B, L):
             work["pw2"][1] += n * (pix[s] * 4 * C * 4 + 2.0 * pix[s] * C * 4)  # hidden in, x in/out
         if s > 0:
             work["downsample"][0] += 2.0 * pix[s] * 4 * DIMS[s - 1] * C
-            work["downsample"][1] += pix[s - 1] * DIMS[s - 1] * 4 + pix[s] * C * 4
-            work["rowstats"][1] += pix[s - 1] * DIMS[s - 1] * 4
+            esz = 2 if precision == "bf16" else 4
+            work["downsample"][1] += pix[s - 1] * DIMS[s - 1] * esz + pix[s] * C * 4
+            work["rowstats"][1] += pix[s - 1] * DIMS[s - 1] * (4 + (esz if precision == "bf16" else 0))
     work["poolhead"] = [2.0 * B * 768 * 527, pix[3] * 768 * 4]
     return work
 
@@ -130,6 +140,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--mode", default="logits", choices=["logits", "scene", "frame"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = BASELINE configs[1] (the headline, 1e-3 parity); bf16 = the arithmetic of configs[2] "
+                         "(bf16 MFMA contractions, fp32 LayerNorm / residual / accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -151,7 +164,8 @@ def main():
     model = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
                           use_speed_perturb=False)
     model.load_state_dict(synth.synth_state_dict(0))
-    model = model.to(dev).eval()
+    model = model.to(dev).eval().set_precision(args.precision)
+    bf16 = args.precision == "bf16"
     B = args.batch
     wav = synth.synth_waveforms(B, CLIP_SAMPLES, seed=1234 + rank).to(dev)
     fn = {"logits": lambda: model(wav)["clipwise_logits"], "scene": lambda: model.forward_scene_embeddings(wav),
@@ -186,9 +200,10 @@ def main():
         "metric": "clips/sec (10 s @ 32 kHz, ConvNeXt-Tiny, bs=64)", "value": world * B * args.steps / elapsed,
         "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": "ConvNeXt-Tiny bs=%d per GPU, synthetic 10 s @ 32 kHz waveforms resident in HBM, "
-                               "waveform -> %s, fp32 (BASELINE configs[1])" % (B, args.mode),
+                               "waveform -> %s, %s" % (B, args.mode, "bf16 contractions with fp32 LayerNorm (arithmetic of "
+                                                       "BASELINE configs[2])" if bf16 else "fp32 (BASELINE configs[1])"),
                    "global_batch": world * B, "clip_samples": CLIP_SAMPLES, "weights": "seeded synthetic (synth.py)",
                    "parallelism": "clips sharded %d-way, full weight replica per GPU, RCCL all-gather of logits"
                                   % world if world > 1 else "single GPU"},
@@ -203,7 +218,7 @@ def main():
         torch.cuda.synchronize(dev)
         prof = ctx.profile_read()
         ctx.profile(False)
-        work = algorithmic_work(B, CLIP_SAMPLES)
+        work = algorithmic_work(B, CLIP_SAMPLES, args.precision)
         kernels = {}
         for k, (ms, n) in prof.items():
             if n == 0:
@@ -216,24 +231,34 @@ def main():
         names = {"pw1": "gemm_f32_kernel (LayerNorm+pwconv1+GELU epilogue, stages 2-3)",
                  "pw2": "gemm_f32_kernel (pwconv2+gamma+residual epilogue, stages 2-3)",
                  "mlp_fused": "mlp_fused_kernel (LN+pwconv1+GELU+pwconv2+residual, stages 0-1)"}
+        if bf16:
+            names = {"pw1": "gemm_bf16_kernel (pwconv1+GELU epilogue, bf16 hidden out)",
+                     "pw2": "gemm_bf16_kernel (pwconv2+gamma+residual epilogue)",
+                     "mlp_fused": "mlp_fused_bf16_kernel"}
+        mfma_peak = MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
         dom = max((k for k in names if k in kernels), key=lambda k: kernels[k]["ms_per_step"])
         per_launch_flops = work[dom][0] / kernels[dom]["launches_per_step"]
         avg_launch_s = kernels[dom]["ms_per_step"] * 1e-3 / kernels[dom]["launches_per_step"]
         ach = per_launch_flops / avg_launch_s / 1e12
         traffic, traffic_src = measured_traffic()
         tr = lambda k: (traffic.get(k, {}).get("hbm_traffic_bytes_per_launch") if B == 64 else None)
-        line["roofline"] = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
-                            "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": tr(dom),
+        line["roofline"] = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": mfma_peak,
+                            "unit": "TFLOP/s", "frac": ach / mfma_peak, "traffic": tr(dom) if not bf16 else None,
                             "traffic_source": traffic_src, "avg_launch_ms": avg_launch_s * 1e3,
                             "flops_per_launch": per_launch_flops,
                             "algorithmic_bytes_per_launch": work[dom][1] / kernels[dom]["launches_per_step"]}
+        if bf16:        # at bf16 rates the GEMMs are bound by their HBM traffic (the hidden activation), not the matrix pipe
+            gbs = work[dom][1] / kernels[dom]["launches_per_step"] / avg_launch_s / 1e9
+            if gbs / HBM_PEAK_GBS > ach / mfma_peak:
+                line["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": gbs / HBM_PEAK_GBS, "mfma_tflops": ach})
         mf = sum(work[k][0] for k in names) / sum(kernels[k]["ms_per_step"] * 1e-3 for k in names if k in kernels) / 1e12
-        line["roofline_all_pointwise"] = {"bound": "mfma", "achieved": mf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                          "frac": mf / MFMA_F32_PEAK_TF}
+        line["roofline_all_pointwise"] = {"bound": "mfma", "achieved": mf, "peak": mfma_peak, "unit": "TFLOP/s",
+                                          "frac": mf / mfma_peak}
         dw = kernels["dwconv"]
         line["roofline_dwconv"] = {"kernel": "dwconv7_kernel", "bound": "hbm", "achieved": dw["algorithmic_GBs"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dw["algorithmic_GBs"] / HBM_PEAK_GBS,
-                                   "traffic": tr("dwconv"), "traffic_source": traffic_src,
+                                   "traffic": tr("dwconv") if not bf16 else None, "traffic_source": traffic_src,
                                    "algorithmic_bytes_per_launch": work["dwconv"][1] / dw["launches_per_step"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()

@@ -53,6 +53,15 @@ enum acx_mode {
     ACX_MODE_FRAME = 2        /* ConvNeXt.forward_frame_embeddings convnext.py:369-402 */
 };
 
+/* Arithmetic of the dense contractions (pwconv1/pwconv2, convnext.py:60-62, and the 2x2 downsample convs,
+ * convnext.py:230-235).  The reference runs everything in fp32; BASELINE configs[2] asks for "bf16 with fp32
+ * LayerNorm": bf16 MFMA operands with fp32 accumulation, while LayerNorm statistics, the residual stream, the
+ * depthwise conv, the frontend and the head stay fp32.  The 1e-3 parity bar applies to ACX_PREC_F32 only. */
+enum acx_precision {
+    ACX_PREC_F32 = 0,
+    ACX_PREC_BF16 = 1
+};
+
 /* kernel classes for acx_profile_read() */
 enum acx_kernel_class {
     ACX_K_FRONTEND = 0, ACX_K_STEM, ACX_K_DWCONV, ACX_K_PW1, ACX_K_PW2, ACX_K_ROWSTATS,
@@ -87,6 +96,11 @@ ACX_API int acx_set_weight(acx_ctx* ctx, const char* state_dict_key, const float
  *   LayerNorm affine folded in.
  * May be called again after weights change. */
 ACX_API int acx_finalize(acx_ctx* ctx);
+
+/* Selects enum acx_precision for every later call (default ACX_PREC_F32; the reference has no such switch --
+ * its torch equivalent is `model.to(torch.bfloat16)` / autocast around the Linear layers).  Changing it drops
+ * the finalized state: call acx_finalize again. */
+ACX_API int acx_set_precision(acx_ctx* ctx, int precision);
 
 /* Geometry helpers: frames T = L/320+1 (torchlibrosa STFT, hop 320, center) and the spatial size
  * after the stem / each downsample (convnext.py:688-691, 230-235). */
