@@ -91,7 +91,7 @@ def stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-PRECISIONS = {"fp32": 0, "bf16": 1}
+PRECISIONS = {"fp32": 0, "bf16": 1, "fp32_split": 2}
 
 
 class Context:

@@ -58,12 +58,17 @@ struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layou
     float* wpack = nullptr;  // [4C/32][64*C]  per hidden chunk: w1 rows [32][C] then w2 columns [C][32] (fused MLP)
     uint16_t* w1h = nullptr; // bf16 mode: [4C][Cp]  folded pwconv1 rounded to bf16, K zero-padded to Cp = pad64(C)
     uint16_t* w2h = nullptr; // bf16 mode: [C][4C]   gamma * pwconv2 rounded to bf16
+    uint16_t* w1s = nullptr; // split mode: folded pwconv1 in S16 form (gemm_split.hip), scaled by w1s_scale
+    uint16_t* w2s = nullptr; // split mode: gamma * pwconv2 in S16 form, scaled by w2s_scale
+    float w1s_scale = 1.f, w2s_scale = 1.f;
 };
 
 struct DownW {           // downsample_layers[i], i>=1 (convnext.py:230-235)
     float* w = nullptr;      // [C'][4C]  k = (dy*2+dx)*C + c, LayerNorm weight folded in
     float* b = nullptr;      // [C']      bias + W . ln_bias
     uint16_t* wh = nullptr;  // bf16 mode: [C'][4*Cp]  k = (dy*2+dx)*Cp + c
+    uint16_t* ws = nullptr;  // split mode: [C'][4C] in S16 form, scaled by ws_scale
+    float ws_scale = 1.f;
 };
 
 struct Profile {
@@ -154,6 +159,17 @@ struct GemmBf16Args {
     int epi; int cls;
 };
 int launch_gemm_bf16(acx_ctx* c, const GemmBf16Args& a, hipStream_t s);
+// fp32 operands as two fp16 halves (gemm_split.hip): A, Wt in S16 form; EPI_GELU writes S16, the others fp32
+constexpr float kSplitLnScale = 2048.0f;      // LayerNorm rows: |LN(y)| <= sqrt(C-1) < 28 -> < 2^15.8
+constexpr float kSplitHiddenScale = 16.0f;    // GELU output, clamped to the fp16 range after scaling
+int launch_layernorm_rows_split(acx_ctx* c, const float* x, void* out, int64_t M, int C, hipStream_t s);
+struct GemmSplitArgs {
+    const void* A; const void* Wt; const float* bias; void* out; const float* resid;
+    int64_t M; int N; int K; float sinv;
+    int gather; int H, W, C, Ho, Wo;
+    int epi; int cls;
+};
+int launch_gemm_split(acx_ctx* c, const GemmSplitArgs& a, hipStream_t s);
 bool mlp_fused_supported(int C);
 // x += MLP(LN(y)) for one block, hidden activation kept in registers (mlp_fused.hip)
 int launch_mlp_fused(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s);

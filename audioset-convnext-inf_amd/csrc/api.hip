@@ -108,6 +108,30 @@ static std::vector<uint16_t> bf16_rows(const std::vector<float>& w, int rows, in
     return h;
 }
 
+// S16 form of gemm_split.hip: [rows][K/8][hi x8 | lo x8] fp16, values pre-multiplied by `scale` (a power of two)
+static std::vector<uint16_t> s16_rows(const std::vector<float>& w, int rows, int K, float scale) {
+    std::vector<uint16_t> h((size_t)rows * K * 2);
+    for (int n = 0; n < rows; ++n)
+        for (int k = 0; k < K; ++k) {
+            const float v = w[(size_t)n * K + k] * scale;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            uint16_t* blk = h.data() + ((size_t)n * K + (size_t)(k & ~7)) * 2;
+            std::memcpy(blk + (k & 7), &hi, 2);
+            std::memcpy(blk + 8 + (k & 7), &lo, 2);
+        }
+    return h;
+}
+
+// power of two that brings max |w| into [2^14, 2^15): both fp16 halves of every weight within 2^13 of the largest
+// stay normal numbers
+static float s16_scale(const std::vector<float>& w) {
+    float mx = 0.f;
+    for (float v : w) mx = std::fmax(mx, std::fabs(v));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.f;
+    return std::ldexp(1.0f, 14 - std::ilogb(mx));
+}
+
 static void free_device(acx_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
@@ -219,6 +243,11 @@ static int finalize_impl(acx_ctx* c) {
         ACX_TRY(upload(c, b, &c->down[i].b));
         c->down[i].wh = nullptr;
         if (c->precision == ACX_PREC_BF16) ACX_TRY(upload(c, bf16_rows(w, Co, 4, Ci, pad64(Ci)), &c->down[i].wh));
+        c->down[i].ws = nullptr;
+        if (c->precision == ACX_PREC_F32_SPLIT) {
+            c->down[i].ws_scale = s16_scale(w);
+            ACX_TRY(upload(c, s16_rows(w, Co, 4 * Ci, c->down[i].ws_scale), &c->down[i].ws));
+        }
     }
     // ---- blocks -----------------------------------------------------------------------------
     for (int s = 0; s < 4; ++s) {
@@ -260,6 +289,12 @@ static int finalize_impl(acx_ctx* c) {
             if (c->precision == ACX_PREC_BF16) {
                 ACX_TRY(upload(c, bf16_rows(f1, 4 * C, 1, C, pad64(C)), &bw.w1h));
                 ACX_TRY(upload(c, bf16_rows(f2, C, 1, 4 * C, 4 * C), &bw.w2h));
+            }
+            if (c->precision == ACX_PREC_F32_SPLIT) {
+                bw.w1s_scale = s16_scale(f1);
+                bw.w2s_scale = s16_scale(f2);
+                ACX_TRY(upload(c, s16_rows(f1, 4 * C, C, bw.w1s_scale), &bw.w1s));
+                ACX_TRY(upload(c, s16_rows(f2, C, 4 * C, bw.w2s_scale), &bw.w2s));
             }
             if (mlp_fused_supported(C)) {       // chunk-major image for the fused kernel's LDS-DMA
                 const int nch = 4 * C / 32;
@@ -332,11 +367,30 @@ static int run_mlp_bf16(acx_ctx* c, const BlockW& bw, int C, const float* y, flo
     return launch_gemm_bf16(c, g2, st);
 }
 
+// split precision: y -> fp32 LayerNorm -> S16 rows IN PLACE (row-local); pwconv1 + GELU -> S16 hidden;
+// pwconv2 + residual -> fp32 x.  Same bytes per element as the fp32 path.
+static int run_mlp_split(acx_ctx* c, const BlockW& bw, int C, float* y, float* x, float* hidden, int64_t M,
+                         hipStream_t st) {
+    ACX_TRY(launch_layernorm_rows_split(c, y, y, M, C, st));
+    GemmSplitArgs g1{};
+    g1.A = y; g1.Wt = bw.w1s; g1.bias = bw.b1; g1.out = hidden; g1.M = M; g1.N = 4 * C; g1.K = C;
+    g1.sinv = 1.0f / (kSplitLnScale * bw.w1s_scale); g1.epi = EPI_GELU; g1.cls = ACX_K_PW1;
+    ACX_TRY(launch_gemm_split(c, g1, st));
+    GemmSplitArgs g2{};
+    g2.A = hidden; g2.Wt = bw.w2s; g2.bias = bw.b2; g2.out = x; g2.resid = x; g2.M = M; g2.N = C; g2.K = 4 * C;
+    g2.sinv = 1.0f / (kSplitHiddenScale * bw.w2s_scale); g2.epi = EPI_RESID; g2.cls = ACX_K_PW2;
+    return launch_gemm_split(c, g2, st);
+}
+
 static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden, float* stats, int B, int H, int Wd,
                      hipStream_t st) {
     const int C = kDims[s];
     const BlockW& bw = c->blocks[s][j];
     const int64_t M = (int64_t)B * H * Wd;
+    if (c->precision == ACX_PREC_F32_SPLIT) {
+        ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
+        return run_mlp_split(c, bw, C, y, x, hidden, M, st);
+    }
     if (c->precision == ACX_PREC_BF16) {
         ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
         return run_mlp_bf16(c, bw, C, y, x, hidden, M, st);
@@ -360,6 +414,15 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
 static int run_downsample(acx_ctx* c, int i, const float* x, float* out, float* xnorm, int B, int H, int Wd,
                           hipStream_t st) {
     const int Ci = kDims[i - 1], Co = kDims[i];
+    if (c->precision == ACX_PREC_F32_SPLIT) {
+        ACX_TRY(launch_layernorm_rows_split(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
+        GemmSplitArgs g{};
+        g.A = xnorm; g.Wt = c->down[i].ws; g.bias = c->down[i].b; g.out = out;
+        g.gather = 1; g.H = H; g.W = Wd; g.C = Ci; g.Ho = H / 2; g.Wo = Wd / 2;
+        g.M = (int64_t)B * g.Ho * g.Wo; g.N = Co; g.K = 4 * Ci; g.sinv = 1.0f / (kSplitLnScale * c->down[i].ws_scale);
+        g.epi = EPI_BIAS; g.cls = ACX_K_DOWNSAMPLE;
+        return launch_gemm_split(c, g, st);
+    }
     if (c->precision == ACX_PREC_BF16) {
         const int Cp = pad64(Ci);
         ACX_TRY(launch_layernorm_rows_bf16(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
@@ -462,7 +525,7 @@ int acx_finalize(acx_ctx* c) {
 
 int acx_set_precision(acx_ctx* c, int precision) {
     if (!c) ACX_FAIL(ACX_ERR_ARG, "null context");
-    if (precision != ACX_PREC_F32 && precision != ACX_PREC_BF16) ACX_FAIL(ACX_ERR_ARG, "acx_set_precision: unknown precision %d", precision);
+    if (precision != ACX_PREC_F32 && precision != ACX_PREC_BF16 && precision != ACX_PREC_F32_SPLIT) ACX_FAIL(ACX_ERR_ARG, "acx_set_precision: unknown precision %d", precision);
     if (precision != c->precision) { c->precision = precision; c->finalized = false; }
     return ACX_OK;
 }
@@ -585,6 +648,9 @@ int acx_block_mlp(acx_ctx* c, int stage, int block, const float* y, const float*
     const BlockW& bw = c->blocks[stage][block];
     const int64_t M = (int64_t)B * H * Wd;
     if (c->precision == ACX_PREC_BF16) return run_mlp_bf16(c, bw, C, y, x, hidden, M, (hipStream_t)stream);
+    if (c->precision == ACX_PREC_F32_SPLIT) {      // y is left untouched: the S16 rows go to the tail of `hidden`... no room: use a copy
+        ACX_FAIL(ACX_ERR_UNSUPPORTED, "acx_block_mlp: split precision normalises y in place; call acx_block instead");
+    }
     if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused(c, bw, C, y, x, M, (hipStream_t)stream);
     GemmArgs g1{};
     g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.colsum = bw.w1sum; g1.M = M; g1.N = 4 * C; g1.K = C;

@@ -298,7 +298,10 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
 // NORMALIZE 1: write (x - mean) * rstd instead (input of the downsample convs, convnext.py:230-235).
 // NORMALIZE 2: the same rounded to bf16, rows padded with zeros to a multiple of 64 channels (A operand of the
 // bf16-precision GEMMs, gemm_bf16.hip); the statistics and the normalisation itself stay fp32.
+// NORMALIZE 3: the same in S16 form (gemm_split.hip): scaled by 2^11, each value as fp16 hi + fp16 lo, blocks of
+// 8 channels = [hi x8][lo x8] -- the same 4 bytes per element as fp32.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int G, int NORMALIZE>
 __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                        long long rows, float eps) {
@@ -331,7 +334,26 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__
 #pragma unroll
         for (int o = G / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
         const float rstd = 1.0f / sqrtf(d * (1.0f / C) + eps);
-        if (NORMALIZE == 2) {
+        if (NORMALIZE == 3) {
+            if (valid) {
+                char* o = reinterpret_cast<char*>(stats) + row * (C * 4);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int f4 = g + G * k;            // float4 index in the row: block f4>>1, half f4&1
+                    f16x4 hi, lo;
+                    const float sc = rstd * kSplitLnScale;
+                    const float t[4] = {(v[k].x - mean) * sc, (v[k].y - mean) * sc, (v[k].z - mean) * sc, (v[k].w - mean) * sc};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hi[e] = (_Float16)t[e];
+                        lo[e] = (_Float16)(t[e] - (float)hi[e]);
+                    }
+                    char* blk = o + (f4 >> 1) * 32 + (f4 & 1) * 8;
+                    *reinterpret_cast<f16x4*>(blk) = hi;
+                    *reinterpret_cast<f16x4*>(blk + 16) = lo;
+                }
+            }
+        } else if (NORMALIZE == 2) {
             if (valid) {
                 constexpr int Cp = (C + 63) / 64 * 64;
                 __bf16* o = reinterpret_cast<__bf16*>(stats) + row * Cp;
@@ -385,6 +407,10 @@ int launch_rowstats(acx_ctx* c, const float* x, float* stats, int64_t M, int C, 
 
 int launch_layernorm_rows(acx_ctx* c, const float* x, float* out, int64_t M, int C, hipStream_t s) {
     return launch_rows<1>(c, x, out, M, C, s);
+}
+
+int launch_layernorm_rows_split(acx_ctx* c, const float* x, void* out, int64_t M, int C, hipStream_t s) {
+    return launch_rows<3>(c, x, reinterpret_cast<float*>(out), M, C, s);
 }
 
 int launch_layernorm_rows_bf16(acx_ctx* c, const float* x, void* out, int64_t M, int C, hipStream_t s) {

@@ -1,0 +1,361 @@
+// K4s/K5s -- the dense contractions with fp32 operands carried as TWO fp16 halves (ACX_PREC_F32_SPLIT).
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the fp16 matrix rate on gfx950 (157 vs 2500 TFLOP/s).  An fp32 value v
+// is v = hi + lo + e with hi = fp16(v), lo = fp16(v - hi), |e| <= 2^-24 |v| (two round-to-nearest 11-bit pieces
+// cover 24 significant bits; gfx950 MFMA honours fp16 subnormals -- tools/mfma_denorm_probe.hip -- and a
+// power-of-two pre-scale keeps the pieces far from the bottom of the fp16 range).  A product of two such values is
+//   a b = ah bh + ah bl + al bh + (al bl ~ 2^-24 a b, dropped),
+// every partial product of two fp16 numbers is exact in fp32 and the matrix core accumulates them in fp32, so three
+// fp16 MFMAs reproduce an fp32 FMA chain to within the rounding of the fp32 accumulation itself -- at 16/3 of the
+// f32-MFMA rate.  tests/test_gpu_parity.py runs its whole suite against this mode at the fp32 tolerances.
+//
+// Operand format "S16" (the same 4 bytes per element as fp32): a row of K values is K/8 blocks of 32 B,
+//   [8 x fp16 hi][8 x fp16 lo];  a 128-B LDS row = 4 blocks = 32 k.  Lane half h of a 32x32x16 MFMA needs 8
+// consecutive k of one row = one block: hi chunk 4s+2h, lo chunk 4s+2h+1 of the row (s = k-step of 16 in the tile).
+// Producers: the LayerNorm pass (dwconv.hip, rows scaled by 2^11: |LN(y)| <= sqrt(C-1) < 28), this kernel's
+// GELU epilogue (hidden activation scaled by 2^4, clamped to the fp16 range) and acx_finalize for the weights
+// (scaled per layer to max |w| in [2^14, 2^15)).  The epilogue multiplies the accumulator by the exact inverse.
+//
+// Tiling / staging as gemm.hip: 128 x BN x 32 per workgroup, both operands by LDS-DMA with the XOR swizzle on the
+// source address, fragments double-buffered in registers.  A k-tile is only 2 x TM*TN*3 MFMAs of 32 cycles, so
+// the pipeline is one k-tile deeper than the fp32 kernel's: tile t+2 is in flight while tile t is multiplied.
+#include "acx_internal.h"
+
+namespace acx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+constexpr int kSRowBytes = 128;     // 32 k per LDS row
+constexpr int kSBK = 32;
+
+__device__ __forceinline__ float gelu_erf_s(float v) {     // see gemm.hip
+    const float av = fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678f, av, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(v * v * -0.72134752f);
+    const float q = pl * t * e;
+    return fmaf(-0.5f * av, q, fmaxf(v, 0.0f));
+}
+
+struct GemmSParams {
+    const char* A; const char* Wt; const float* bias; void* out; const float* resid;
+    long long M; int N; int K;
+    float sinv;                // 1 / (scale of A * scale of Wt)
+    int H, W, C, Ho, Wo;       // gather mode: A is (B,H,W,C) S16 rows; row m = (b,ho,wo), k = (dy*2+dx)*C + c
+    int tiles_n;
+};
+
+__device__ __forceinline__ void lds_dma16_s(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// EPI: 0 bias -> fp32, 1 bias + GELU -> S16 (scaled by kHiddenScale), 2 bias + residual -> fp32
+template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
+__global__ __launch_bounds__(256) void gemm_split_kernel(GemmSParams p) {
+    constexpr int TM = kBM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr int A_TILE = kBM * kSRowBytes, B_TILE = BN * kSRowBytes;
+    constexpr int A_DMA = kBM / 32, B_DMA = BN / 32;
+    constexpr bool SWAP = (EPI == 1);      // D = (W A^T): lane = m, registers = 4 consecutive n -> packed S16 stores
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + 2 * A_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    long long lid = blockIdx.x;
+    {   // XCD-contiguous tile order (see gemm.hip)
+        const long long nwg = gridDim.x, per = (nwg + 7) >> 3, full = nwg - (per - 1) * 8;
+        const long long xcd = lid & 7, k = lid >> 3;
+        lid = (xcd < full ? xcd * per : full * per + (xcd - full) * (per - 1)) + k;
+    }
+    const int tile_n = (int)(lid % p.tiles_n);
+    const long long tile_m = lid / p.tiles_n;
+    const long long m0 = tile_m * kBM;
+    const int n0 = tile_n * BN;
+
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const char* a_src[A_DMA];
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i) {
+        const int row = A_DMA * 8 * wave + 8 * i + prow;
+        const int chunk = pchunk ^ ((row >> 1) & 7);
+        long long m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        if (GATHER) {
+            const int wo = (int)(m % p.Wo);
+            const long long t = m / p.Wo;
+            const int ho = (int)(t % p.Ho);
+            const long long b = t / p.Ho;
+            a_src[i] = p.A + (((b * p.H + 2 * ho) * p.W + 2 * wo) * p.C) * 4 + 16 * chunk;
+        } else {
+            a_src[i] = p.A + m * p.K * 4 + 16 * chunk;
+        }
+    }
+    const char* b_src[B_DMA];
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i) {
+        const int row = B_DMA * 8 * wave + 8 * i + prow;
+        const int chunk = pchunk ^ ((row >> 1) & 7);
+        b_src[i] = p.Wt + (long long)(n0 + row) * p.K * 4 + 16 * chunk;
+    }
+    char* a_dst = As + A_DMA * 8 * wave * kSRowBytes;
+    char* b_dst = Bs + B_DMA * 8 * wave * kSRowBytes;
+    auto a_koff = [&](int k0) -> long long {        // byte offset of k-tile k0 inside an A row
+        if (GATHER) {
+            const int qd = k0 / p.C;
+            return ((long long)((qd >> 1) * p.W + (qd & 1)) * p.C + (k0 - qd * p.C)) * 4;
+        }
+        return (long long)k0 * 4;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sw = (l31 >> 1) & 7;
+    int foff_hi[2], foff_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        foff_hi[s] = l31 * kSRowBytes + (((4 * s + 2 * hh) ^ sw) << 4);
+        foff_lo[s] = l31 * kSRowBytes + (((4 * s + 2 * hh + 1) ^ sw) << 4);
+    }
+    const int a_frag_off = wm * TM * 32 * kSRowBytes;
+    const int b_frag_off = wn * TN * 32 * kSRowBytes;
+#define ACX_READ_FRAGS(F, abase, bbase, s)                                                              \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
+            F##ah[i] = *reinterpret_cast<const f32x4*>((abase) + i * 32 * kSRowBytes + foff_hi[s]);    \
+            F##al[i] = *reinterpret_cast<const f32x4*>((abase) + i * 32 * kSRowBytes + foff_lo[s]);    \
+        }                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                               \
+            F##bh[j] = *reinterpret_cast<const f32x4*>((bbase) + j * 32 * kSRowBytes + foff_hi[s]);    \
+            F##bl[j] = *reinterpret_cast<const f32x4*>((bbase) + j * 32 * kSRowBytes + foff_lo[s]);    \
+        }                                                                                              \
+    }
+#define ACX_H8(x) __builtin_bit_cast(h8, x)
+#define ACX_MFMA3(i, j, F)                                                                             \
+    if (SWAP) {                                                                                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bl[j]), ACX_H8(F##ah[i]), acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bh[j]), ACX_H8(F##al[i]), acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bh[j]), ACX_H8(F##ah[i]), acc[i][j], 0, 0, 0); \
+    } else {                                                                                           \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##al[i]), ACX_H8(F##bh[j]), acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##ah[i]), ACX_H8(F##bl[j]), acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##ah[i]), ACX_H8(F##bh[j]), acc[i][j], 0, 0, 0); \
+    }
+#define ACX_MFMA_STEP(F)                                                                               \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) { ACX_MFMA3(i, j, F) }                          \
+    }
+    // the same with the LDS-DMA pieces of a later tile threaded between the (i,j) triples
+#define ACX_MFMA_STEP_DMA(F, koffA, k0B, buf)                                                          \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                               \
+            constexpr int NP = (A_DMA + B_DMA + TM * TN - 1) / (TM * TN);                              \
+            _Pragma("unroll") for (int q = 0; q < NP; ++q) {                                           \
+                const int pc = (i * TN + j) * NP + q;                                                  \
+                if (pc < A_DMA) lds_dma16_s(a_src[pc] + (koffA), a_dst + (buf) * A_TILE + pc * 8 * kSRowBytes); \
+                else if (pc < A_DMA + B_DMA)                                                           \
+                    lds_dma16_s(b_src[pc - A_DMA] + (k0B), b_dst + (buf) * B_TILE + (pc - A_DMA) * 8 * kSRowBytes); \
+            }                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            ACX_MFMA3(i, j, F)                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+        }                                                                                              \
+    }
+#define ACX_DMA_TILE(koffA, k0B, buf)                                                                  \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < A_DMA; ++i)                                              \
+            lds_dma16_s(a_src[i] + (koffA), a_dst + (buf) * A_TILE + i * 8 * kSRowBytes);              \
+        _Pragma("unroll") for (int i = 0; i < B_DMA; ++i)                                              \
+            lds_dma16_s(b_src[i] + (k0B), b_dst + (buf) * B_TILE + i * 8 * kSRowBytes);                \
+    }
+#define ACX_TOUCH(F)      /* see gemm.hip: keeps hipcc's lgkmcnt(0) off freshly issued reads */        \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) { asm volatile("" :: "v"(F##ah[i])); asm volatile("" :: "v"(F##al[i])); } \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) { asm volatile("" :: "v"(F##bh[j])); asm volatile("" :: "v"(F##bl[j])); } \
+    }
+
+    const int nk = p.K / kSBK;
+    // prologue: tiles 0 and 1 in flight, fragments of tile 0 in registers
+    ACX_DMA_TILE(a_koff(0), 0LL, 0)
+    __syncthreads();
+    if (nk > 1) ACX_DMA_TILE(a_koff(kSBK), (long long)kSBK * 4, 1)
+    f32x4 F0ah[TM], F0al[TM], F0bh[TN], F0bl[TN], F1ah[TM], F1al[TM], F1bh[TN], F1bl[TN];
+    {
+        const char* ab = As + a_frag_off;
+        const char* bb = Bs + b_frag_off;
+        ACX_READ_FRAGS(F0, ab, bb, 0)
+        ACX_READ_FRAGS(F1, ab, bb, 1)
+    }
+    // steady state, tile t:  MFMA s0 | barrier (tile t+1 landed, tile t fully read) | rd s0(t+1) |
+    //                        MFMA s1 threaded with DMA(t+2 -> buffer of t) | rd s1(t+1)
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
+        const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_STEP(F0)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(F1)
+        __syncthreads();
+        ACX_READ_FRAGS(F0, abn, bbn, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) {
+            const int k2 = (kt + 2) * kSBK;
+            const long long ka = a_koff(k2);
+            ACX_MFMA_STEP_DMA(F1, ka, (long long)k2 * 4, kt & 1)
+        } else {
+            ACX_MFMA_STEP(F1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(F0)
+        ACX_READ_FRAGS(F1, abn, bbn, 1)
+    }
+    ACX_MFMA_STEP(F0)
+    ACX_MFMA_STEP(F1)
+#undef ACX_READ_FRAGS
+#undef ACX_MFMA3
+#undef ACX_MFMA_STEP
+#undef ACX_MFMA_STEP_DMA
+#undef ACX_DMA_TILE
+#undef ACX_TOUCH
+#undef ACX_H8
+
+    const float sinv = p.sinv;
+    if (SWAP) {
+        // ---- GELU epilogue, D = W A^T: lane = row m, registers r = 4q+e hold n = 8q + 4hh + e ------------------
+        // One S16 block (8 n) = [hi x8][lo x8] is shared by the lane pair (l31, hh=0/1): after a permlane32 swap
+        // the low lane holds all 8 hi halves and the high lane all 8 lo halves -> one 16-B store each.
+        char* outb = reinterpret_cast<char*>(p.out);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long long m = m0 + (wm * TM + i) * 32 + l31;
+            const bool ok = m < p.M;
+            char* orow = outb + (ok ? m : 0) * p.N * 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nb = n0 + (wn * TN + j) * 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * q + 4 * hh);
+                    unsigned xh[2], xl[2];
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        _Float16 h[2], l[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int e = 2 * e2 + u;
+                            float v = gelu_erf_s(fmaf(acc[i][j][4 * q + e], sinv, b4[e])) * kSplitHiddenScale;
+                            v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+                            h[u] = (_Float16)v;
+                            l[u] = (_Float16)(v - (float)h[u]);
+                        }
+                        h2 ph, pl;
+                        ph[0] = h[0]; ph[1] = h[1]; pl[0] = l[0]; pl[1] = l[1];
+                        xh[e2] = __builtin_bit_cast(unsigned, ph);
+                        xl[e2] = __builtin_bit_cast(unsigned, pl);
+                    }
+                    // low lanes: (own hi, partner hi); high lanes: (partner lo, own lo)
+                    auto r0 = __builtin_amdgcn_permlane32_swap(xh[0], xl[0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(xh[1], xl[1], false, false);
+                    uint4 o;
+                    o.x = r0[0]; o.y = r1[0]; o.z = r0[1]; o.w = r1[1];
+                    if (ok) *reinterpret_cast<uint4*>(orow + (long long)(nb + 8 * q) * 4 + 16 * hh) = o;
+                }
+            }
+        }
+    } else {
+        // ---- fp32 epilogue: D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ------------
+        float* outf = reinterpret_cast<float*>(p.out);
+        const bool full = m0 + kBM <= p.M;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long long mb = m0 + (wm * TM + i) * 32 + 4 * hh;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + l31;
+                const float bn = p.bias[n];
+                float* op = outf + mb * p.N + n;
+                const float* rp = (EPI == 2) ? p.resid + mb * p.N + n : nullptr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (full || mb + dr < p.M) {
+                        const long long off = (long long)dr * p.N;
+                        float v = fmaf(acc[i][j][r], sinv, bn);
+                        if (EPI == 2) v += rp[off];
+                        op[off] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
+static int launch_s_cfg(const GemmSParams& p0, hipStream_t s) {
+    GemmSParams p = p0;
+    p.tiles_n = p.N / BN;
+    const long long tiles_m = (p.M + kBM - 1) / kBM;
+    const long long blocks = tiles_m * p.tiles_n;
+    if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: grid too large");
+    constexpr size_t lds = (size_t)2 * (kBM + BN) * kSRowBytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(p);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
+template <int EPI, int GATHER>
+static int launch_s_bn(const GemmSParams& p, hipStream_t s) {
+    const long long tiles128 = ((p.M + 127) / 128) * (p.N % 128 == 0 ? p.N / 128 : p.N / 96);
+    const bool small = tiles128 < 800;
+    if (p.N % 128 == 0) {
+        if (small) return launch_s_cfg<64, 128, 2, 2, EPI, GATHER>(p, s);
+        return launch_s_cfg<128, 128, 2, 2, EPI, GATHER>(p, s);
+    }
+    if (p.N % 96 == 0) return launch_s_cfg<128, 96, 4, 1, EPI, GATHER>(p, s);
+    ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: N=%d is not a multiple of 96 or 128", p.N);
+}
+
+int launch_gemm_split(acx_ctx* c, const GemmSplitArgs& a, hipStream_t s) {
+    if (a.K % kSBK != 0) ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: K=%d is not a multiple of %d", a.K, kSBK);
+    if (a.M <= 0) return ACX_OK;
+    GemmSParams p;
+    p.A = reinterpret_cast<const char*>(a.A); p.Wt = reinterpret_cast<const char*>(a.Wt); p.bias = a.bias;
+    p.out = a.out; p.resid = a.resid; p.M = a.M; p.N = a.N; p.K = a.K; p.sinv = a.sinv;
+    p.H = a.H; p.W = a.W; p.C = a.C; p.Ho = a.Ho; p.Wo = a.Wo; p.tiles_n = 0;
+    ProfScope ps(c, a.cls, s);
+    if (a.gather) {
+        if (a.epi != EPI_BIAS || a.C % kSBK != 0) ACX_FAIL(ACX_ERR_ARG, "gemm_split: bad gather configuration");
+        return launch_s_bn<0, 1>(p, s);
+    }
+    if (a.epi == EPI_GELU) return launch_s_bn<1, 0>(p, s);
+    if (a.epi == EPI_RESID) return launch_s_bn<2, 0>(p, s);
+    if (a.epi == EPI_BIAS) return launch_s_bn<0, 0>(p, s);
+    ACX_FAIL(ACX_ERR_ARG, "gemm_split: unknown epilogue %d", a.epi);
+}
+
+}  // namespace acx

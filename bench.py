@@ -61,7 +61,13 @@ def algorithmic_work(B, L, precision="fp32"):
         n = DEPTHS[s]
         work["dwconv"][0] += n * 2.0 * 49 * pix[s] * C
         work["dwconv"][1] += n * 2.0 * pix[s] * C * 4                      # read x, write y
-        if precision == "bf16":
+        if precision == "fp32_split":
+            work["rowstats"][1] += n * 2.0 * pix[s] * C * 4                    # LayerNorm -> S16 rows, in place
+            work["pw1"][0] += n * 2.0 * pix[s] * C * 4 * C
+            work["pw1"][1] += n * (pix[s] * C * 4 + pix[s] * 4 * C * 4)
+            work["pw2"][0] += n * 2.0 * pix[s] * C * 4 * C
+            work["pw2"][1] += n * (pix[s] * 4 * C * 4 + 2.0 * pix[s] * C * 4)
+        elif precision == "bf16":
             Cp = (C + 63) // 64 * 64
             work["rowstats"][1] += n * (pix[s] * C * 4 + pix[s] * Cp * 2)
             work["pw1"][0] += n * 2.0 * pix[s] * C * 4 * C
@@ -81,7 +87,7 @@ def algorithmic_work(B, L, precision="fp32"):
             work["downsample"][0] += 2.0 * pix[s] * 4 * DIMS[s - 1] * C
             esz = 2 if precision == "bf16" else 4
             work["downsample"][1] += pix[s - 1] * DIMS[s - 1] * esz + pix[s] * C * 4
-            work["rowstats"][1] += pix[s - 1] * DIMS[s - 1] * (4 + (esz if precision == "bf16" else 0))
+            work["rowstats"][1] += pix[s - 1] * DIMS[s - 1] * (4 + (esz if precision != "fp32" else 0))
     work["poolhead"] = [2.0 * B * 768 * 527, pix[3] * 768 * 4]
     return work
 
@@ -140,7 +146,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--mode", default="logits", choices=["logits", "scene", "frame"])
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32_split"],
                     help="fp32 = BASELINE configs[1] (the headline, 1e-3 parity); bf16 = the arithmetic of configs[2] "
                          "(bf16 MFMA contractions, fp32 LayerNorm / residual / accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -58,8 +58,11 @@ enum acx_mode {
  * LayerNorm": bf16 MFMA operands with fp32 accumulation, while LayerNorm statistics, the residual stream, the
  * depthwise conv, the frontend and the head stay fp32.  The 1e-3 parity bar applies to ACX_PREC_F32 only. */
 enum acx_precision {
-    ACX_PREC_F32 = 0,
-    ACX_PREC_BF16 = 1
+    ACX_PREC_F32 = 0,         /* v_mfma_f32_32x32x2_f32: fp32 operands on the matrix cores */
+    ACX_PREC_BF16 = 1,        /* bf16 operands, fp32 accumulate (NOT within the 1e-3 bar) */
+    ACX_PREC_F32_SPLIT = 2    /* fp32 operands carried as fp16 hi + fp16 lo (24 significant bits), three fp16
+                               * MFMAs per product, fp32 accumulate: fp32-grade results (same parity tests and
+                               * tolerances as ACX_PREC_F32) at 16/3 of the f32-MFMA rate */
 };
 
 /* kernel classes for acx_profile_read() */
