@@ -60,6 +60,7 @@ struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layou
     uint16_t* w2h = nullptr; // bf16 mode: [C][4C]   gamma * pwconv2 rounded to bf16
     uint16_t* w1s = nullptr; // split mode: folded pwconv1 in S16 form (gemm_split.hip), scaled by w1s_scale
     uint16_t* w2s = nullptr; // split mode: gamma * pwconv2 in S16 form, scaled by w2s_scale
+    uint16_t* wpack_s = nullptr; // split mode, C = 96/192: chunk-major [W1c | W2c] S16 image (mlp_fused_split.hip)
     float w1s_scale = 1.f, w2s_scale = 1.f;
 };
 
@@ -173,6 +174,7 @@ int launch_gemm_split(acx_ctx* c, const GemmSplitArgs& a, hipStream_t s);
 bool mlp_fused_supported(int C);
 // x += MLP(LN(y)) for one block, hidden activation kept in registers (mlp_fused.hip)
 int launch_mlp_fused(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s);
+int launch_mlp_fused_split(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s);
 int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
                      hipStream_t s);
 int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, int W, int C, hipStream_t s);

@@ -293,8 +293,32 @@ static int finalize_impl(acx_ctx* c) {
             if (c->precision == ACX_PREC_F32_SPLIT) {
                 bw.w1s_scale = s16_scale(f1);
                 bw.w2s_scale = s16_scale(f2);
-                ACX_TRY(upload(c, s16_rows(f1, 4 * C, C, bw.w1s_scale), &bw.w1s));
+                const std::vector<uint16_t> h1 = s16_rows(f1, 4 * C, C, bw.w1s_scale);
+                ACX_TRY(upload(c, h1, &bw.w1s));
                 ACX_TRY(upload(c, s16_rows(f2, C, 4 * C, bw.w2s_scale), &bw.w2s));
+                if (mlp_fused_supported(C)) {
+                    // chunk-major image for mlp_fused_split.hip: per chunk j [W1c = rows 32j..32j+31 of w1s]
+                    // [W2c: C rows x 4 blocks; block b = 2s'+h holds hidden units 32j + 16s' + 4h + 8(jj>>2) + (jj&3)]
+                    const int nch = 4 * C / 32;
+                    const size_t half = (size_t)64 * C;                    // uint16 elements per [32][C] S16 image
+                    std::vector<uint16_t> pk((size_t)nch * 2 * half);
+                    for (int j = 0; j < nch; ++j) {
+                        uint16_t* blk = pk.data() + (size_t)j * 2 * half;
+                        std::memcpy(blk, h1.data() + (size_t)j * half, half * 2);
+                        uint16_t* blk2 = blk + half;
+                        for (int ch = 0; ch < C; ++ch)
+                            for (int b = 0; b < 4; ++b)
+                                for (int jj = 0; jj < 8; ++jj) {
+                                    const int u = 32 * j + 16 * (b >> 1) + 4 * (b & 1) + 8 * (jj >> 2) + (jj & 3);
+                                    const float v = f2[(size_t)ch * 4 * C + u] * bw.w2s_scale;
+                                    const _Float16 hi = (_Float16)v;
+                                    const _Float16 lo = (_Float16)(v - (float)hi);
+                                    std::memcpy(blk2 + (size_t)ch * 64 + b * 16 + jj, &hi, 2);
+                                    std::memcpy(blk2 + (size_t)ch * 64 + b * 16 + 8 + jj, &lo, 2);
+                                }
+                    }
+                    ACX_TRY(upload(c, pk, &bw.wpack_s));
+                }
             }
             if (mlp_fused_supported(C)) {       // chunk-major image for the fused kernel's LDS-DMA
                 const int nch = 4 * C / 32;
@@ -389,6 +413,7 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     const int64_t M = (int64_t)B * H * Wd;
     if (c->precision == ACX_PREC_F32_SPLIT) {
         ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
+        if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused_split(c, bw, C, y, x, M, st);
         return run_mlp_split(c, bw, C, y, x, hidden, M, st);
     }
     if (c->precision == ACX_PREC_BF16) {

@@ -52,6 +52,9 @@ struct GemmSParams {
 };
 
 __device__ __forceinline__ void lds_dma16_s(const char* gsrc, char* lds_wave_base) {
+#ifdef ACX_SLAB_NO_DMA      // diagnostic: no operand traffic at all (LDS holds garbage)
+    return;
+#endif
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
@@ -148,35 +151,34 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSParams p) {
         }                                                                                              \
     }
 #define ACX_H8(x) __builtin_bit_cast(h8, x)
-#define ACX_MFMA3(i, j, F)                                                                             \
+#define ACX_MFMA1(term, i, j, F)     /* term 0: lo x hi, 1: hi x lo, 2: hi x hi */                      \
     if (SWAP) {                                                                                        \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bl[j]), ACX_H8(F##ah[i]), acc[i][j], 0, 0, 0); \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bh[j]), ACX_H8(F##al[i]), acc[i][j], 0, 0, 0); \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bh[j]), ACX_H8(F##ah[i]), acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8((term) == 0 ? F##bl[j] : F##bh[j]),  \
+                                                           ACX_H8((term) == 1 ? F##al[i] : F##ah[i]), acc[i][j], 0, 0, 0); \
     } else {                                                                                           \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##al[i]), ACX_H8(F##bh[j]), acc[i][j], 0, 0, 0); \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##ah[i]), ACX_H8(F##bl[j]), acc[i][j], 0, 0, 0); \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##ah[i]), ACX_H8(F##bh[j]), acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8((term) == 0 ? F##al[i] : F##ah[i]),  \
+                                                           ACX_H8((term) == 1 ? F##bl[j] : F##bh[j]), acc[i][j], 0, 0, 0); \
     }
+    // term-major order: MFMAs on the same accumulator are TM*TN instructions apart
 #define ACX_MFMA_STEP(F)                                                                               \
     {                                                                                                  \
+        _Pragma("unroll") for (int term = 0; term < 3; ++term)                                         \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) { ACX_MFMA3(i, j, F) }                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) { ACX_MFMA1(term, i, j, F) }                    \
     }
-    // the same with the LDS-DMA pieces of a later tile threaded between the (i,j) triples
+    // the same with the LDS-DMA pieces of a later tile threaded in, one piece in front of each MFMA
 #define ACX_MFMA_STEP_DMA(F, koffA, k0B, buf)                                                          \
     {                                                                                                  \
+        static_assert(A_DMA + B_DMA <= 3 * TM * TN, "one DMA piece per MFMA");                         \
+        _Pragma("unroll") for (int term = 0; term < 3; ++term)                                         \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                               \
-            constexpr int NP = (A_DMA + B_DMA + TM * TN - 1) / (TM * TN);                              \
-            _Pragma("unroll") for (int q = 0; q < NP; ++q) {                                           \
-                const int pc = (i * TN + j) * NP + q;                                                  \
-                if (pc < A_DMA) lds_dma16_s(a_src[pc] + (koffA), a_dst + (buf) * A_TILE + pc * 8 * kSRowBytes); \
-                else if (pc < A_DMA + B_DMA)                                                           \
-                    lds_dma16_s(b_src[pc - A_DMA] + (k0B), b_dst + (buf) * B_TILE + (pc - A_DMA) * 8 * kSRowBytes); \
-            }                                                                                          \
+            const int pc = (term * TM + i) * TN + j;                                                   \
+            if (pc < A_DMA) lds_dma16_s(a_src[pc] + (koffA), a_dst + (buf) * A_TILE + pc * 8 * kSRowBytes); \
+            else if (pc < A_DMA + B_DMA)                                                               \
+                lds_dma16_s(b_src[pc - A_DMA] + (k0B), b_dst + (buf) * B_TILE + (pc - A_DMA) * 8 * kSRowBytes); \
             __builtin_amdgcn_sched_barrier(0);                                                         \
-            ACX_MFMA3(i, j, F)                                                                         \
+            ACX_MFMA1(term, i, j, F)                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                         \
         }                                                                                              \
     }
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSParams p) {
     // prologue: tiles 0 and 1 in flight, fragments of tile 0 in registers
     ACX_DMA_TILE(a_koff(0), 0LL, 0)
     __syncthreads();
-    if (nk > 1) ACX_DMA_TILE(a_koff(kSBK), (long long)kSBK * 4, 1)
+    ACX_DMA_TILE(a_koff(kSBK), (long long)kSBK * 4, 1)         // nk >= 2 (checked by the launcher)
     f32x4 F0ah[TM], F0al[TM], F0bh[TN], F0bl[TN], F1ah[TM], F1al[TM], F1bh[TN], F1bl[TN];
     {
         const char* ab = As + a_frag_off;
@@ -207,7 +209,27 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSParams p) {
     }
     // steady state, tile t:  MFMA s0 | barrier (tile t+1 landed, tile t fully read) | rd s0(t+1) |
     //                        MFMA s1 threaded with DMA(t+2 -> buffer of t) | rd s1(t+1)
-    for (int kt = 0; kt + 1 < nk; ++kt) {
+    // (no conditional inside the loop: a branch around the DMA variant makes hipcc copy all accumulators twice
+    //  per iteration)
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
+        const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
+        const int k2 = (kt + 2) * kSBK;
+        const long long ka = a_koff(k2);
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_STEP(F0)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(F1)
+        __syncthreads();
+        ACX_READ_FRAGS(F0, abn, bbn, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_MFMA_STEP_DMA(F1, ka, (long long)k2 * 4, kt & 1)
+        __builtin_amdgcn_sched_barrier(0);
+        ACX_TOUCH(F0)
+        ACX_READ_FRAGS(F1, abn, bbn, 1)
+    }
+    {   // tile nk-2: nothing left to fetch
         const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
         const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
         __builtin_amdgcn_sched_barrier(0);
@@ -217,13 +239,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSParams p) {
         __syncthreads();
         ACX_READ_FRAGS(F0, abn, bbn, 0)
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk) {
-            const int k2 = (kt + 2) * kSBK;
-            const long long ka = a_koff(k2);
-            ACX_MFMA_STEP_DMA(F1, ka, (long long)k2 * 4, kt & 1)
-        } else {
-            ACX_MFMA_STEP(F1)
-        }
+        ACX_MFMA_STEP(F1)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(F0)
         ACX_READ_FRAGS(F1, abn, bbn, 1)
@@ -231,13 +247,22 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSParams p) {
     ACX_MFMA_STEP(F0)
     ACX_MFMA_STEP(F1)
 #undef ACX_READ_FRAGS
-#undef ACX_MFMA3
+#undef ACX_MFMA1
 #undef ACX_MFMA_STEP
 #undef ACX_MFMA_STEP_DMA
 #undef ACX_DMA_TILE
 #undef ACX_TOUCH
 #undef ACX_H8
 
+#ifdef ACX_SLAB_NO_EPI      // diagnostic (tools/split_lab.hip): main loop only
+    {
+        float t = 0.f;
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) reinterpret_cast<float*>(p.out)[tid] = t;
+        return;
+    }
+#endif
     const float sinv = p.sinv;
     if (SWAP) {
         // ---- GELU epilogue, D = W A^T: lane = row m, registers r = 4q+e hold n = 8q + 4hh + e ------------------
@@ -341,7 +366,7 @@ static int launch_s_bn(const GemmSParams& p, hipStream_t s) {
 }
 
 int launch_gemm_split(acx_ctx* c, const GemmSplitArgs& a, hipStream_t s) {
-    if (a.K % kSBK != 0) ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: K=%d is not a multiple of %d", a.K, kSBK);
+    if (a.K % kSBK != 0 || a.K < 2 * kSBK) ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: K=%d is not a multiple of %d >= %d", a.K, kSBK, 2 * kSBK);
     if (a.M <= 0) return ACX_OK;
     GemmSParams p;
     p.A = reinterpret_cast<const char*>(a.A); p.Wt = reinterpret_cast<const char*>(a.Wt); p.bias = a.bias;
