@@ -20,28 +20,13 @@
 // source address, fragments double-buffered in registers.  A k-tile is only 2 x TM*TN*3 MFMAs of 32 cycles, so
 // the pipeline is one k-tile deeper than the fp32 kernel's: tile t+2 is in flight while tile t is multiplied.
 #include "acx_internal.h"
+#include "split_math.h"
 
 namespace acx {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSRowBytes = 128;     // 32 k per LDS row
 constexpr int kSBK = 32;
-
-__device__ __forceinline__ float gelu_erf_s(float v) {     // see gemm.hip
-    const float av = fabsf(v);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678f, av, 1.0f));
-    float pl = fmaf(1.061405429f, t, -1.453152027f);
-    pl = fmaf(pl, t, 1.421413741f);
-    pl = fmaf(pl, t, -0.284496736f);
-    pl = fmaf(pl, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(v * v * -0.72134752f);
-    const float q = pl * t * e;
-    return fmaf(-0.5f * av, q, fmaxf(v, 0.0f));
-}
 
 struct GemmSParams {
     const char* A; const char* Wt; const float* bias; void* out; const float* resid;
@@ -265,6 +250,12 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSParams p) {
 #endif
     const float sinv = p.sinv;
     if (SWAP) {
+        GeluConsts gk;          // GELU of v = a * sinv, result x kSplitHiddenScale (see split_math.h)
+        gk.ps = 0.3275911f * 0.70710678f * sinv;
+        gk.cs = -0.72134752f * sinv * sinv;
+        gk.ca = -0.5f * sinv * kSplitHiddenScale;
+        gk.cb = sinv * kSplitHiddenScale;
+        const float binv = 1.0f / sinv;     // a power of two
         // ---- GELU epilogue, D = W A^T: lane = row m, registers r = 4q+e hold n = 8q + 4hh + e ------------------
         // One S16 block (8 n) = [hi x8][lo x8] is shared by the lane pair (l31, hh=0/1): after a permlane32 swap
         // the low lane holds all 8 hi halves and the high lane all 8 lo halves -> one 16-B store each.
@@ -282,20 +273,13 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSParams p) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * q + 4 * hh);
                     unsigned xh[2], xl[2];
 #pragma unroll
-                    for (int e2 = 0; e2 < 2; ++e2) {
-                        _Float16 h[2], l[2];
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int e = 2 * e2 + u;
-                            float v = gelu_erf_s(fmaf(acc[i][j][4 * q + e], sinv, b4[e])) * kSplitHiddenScale;
-                            v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
-                            h[u] = (_Float16)v;
-                            l[u] = (_Float16)(v - (float)h[u]);
-                        }
-                        h2 ph, pl;
-                        ph[0] = h[0]; ph[1] = h[1]; pl[0] = l[0]; pl[1] = l[1];
-                        xh[e2] = __builtin_bit_cast(unsigned, ph);
-                        xl[e2] = __builtin_bit_cast(unsigned, pl);
+                    for (int e2 = 0; e2 < 2; ++e2) {      // acc holds v / sinv - bias / sinv: add the pre-scaled bias first
+                        f32x2 a2, av, t, ex, g;
+                        a2.x = acc[i][j][4 * q + 2 * e2] + b4[2 * e2] * binv;
+                        a2.y = acc[i][j][4 * q + 2 * e2 + 1] + b4[2 * e2 + 1] * binv;
+                        gelu_piece1(a2, gk, av, t, ex);
+                        gelu_piece2(a2, av, t, ex, gk, g);
+                        gelu_piece3(g, xh[e2], xl[e2]);
                     }
                     // low lanes: (own hi, partner hi); high lanes: (partner lo, own lo)
                     auto r0 = __builtin_amdgcn_permlane32_swap(xh[0], xl[0], false, false);
@@ -357,6 +341,10 @@ template <int EPI, int GATHER>
 static int launch_s_bn(const GemmSParams& p, hipStream_t s) {
     const long long tiles128 = ((p.M + 127) / 128) * (p.N % 128 == 0 ? p.N / 128 : p.N / 96);
     const bool small = tiles128 < 800;
+#ifdef ACX_SPLIT_BIG
+    if (p.N % 256 == 0 && p.K >= 384) return launch_s_cfg<256, 256, 2, 2, EPI, GATHER>(p, s);
+    if (p.N % 128 == 0 && p.K >= 384) return launch_s_cfg<256, 128, 2, 2, EPI, GATHER>(p, s);
+#endif
     if (p.N % 128 == 0) {
         if (small) return launch_s_cfg<64, 128, 2, 2, EPI, GATHER>(p, s);
         return launch_s_cfg<128, 128, 2, 2, EPI, GATHER>(p, s);

@@ -15,45 +15,30 @@
 //               with the hidden units of each chunk in exactly that order (acx_finalize), so its fragments are
 //               plain 16-B reads.
 // HBM traffic per block: read y, read x, write x.
+//
+// Schedule (per wave, iteration j over the 4C/32 hidden chunks) -- three independent instruction streams:
+//     matrix  A: phase 1 of chunk j+2 (chained on one accumulator)       B: phase 2 of chunk j
+//     vector  GELU + split of chunk j+1, cut into 24 pieces (8 register pairs x 3 sub-steps of ~9 instructions)
+//             that are dealt over the (k-step | out-tile) units of A and B: each unit is 3 MFMAs = 96 matrix cycles
+//             of which 72 are free for vector issue
+//     LDS     fragments of unit u+1 are read while unit u multiplies (two named register pairs)
+//     DMA     [W1c | W2c] images run kLead iterations ahead in rings of kLead+1 slots; the end-of-iteration wait is
+//             a counted s_waitcnt vmcnt(N) + bare s_barrier so that the youngest images stay in flight (a
+//             __syncthreads() would drain them: hipcc puts vmcnt(0) in front of it)
+#include <type_traits>
+
 #include "acx_internal.h"
+#include "split_math.h"
 
 namespace acx {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 bc2(float v) { f32x2 r; r.x = v; r.y = v; return r; }
-
-// v = a * s;  g = gelu_erf(v) * kH (A&S 7.1.26, see gemm.hip) for two values, returned as packed fp16 hi / lo halves
-struct GeluConsts { float ps, cs, ca, cb; };
-__device__ __forceinline__ void gelu_split2(f32x2 a, const GeluConsts& k, unsigned& hi, unsigned& lo) {
-    f32x2 av;
-    av.x = __builtin_fabsf(a.x); av.y = __builtin_fabsf(a.y);
-    const f32x2 den = fma2(av, bc2(k.ps), bc2(1.0f));
-    f32x2 t;
-    t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
-    f32x2 pl = fma2(t, bc2(1.061405429f), bc2(-1.453152027f));
-    pl = fma2(pl, t, bc2(1.421413741f));
-    pl = fma2(pl, t, bc2(-0.284496736f));
-    pl = fma2(pl, t, bc2(0.254829592f));
-    const f32x2 ex = a * a * bc2(k.cs);
-    f32x2 e;
-    e.x = __builtin_amdgcn_exp2f(ex.x); e.y = __builtin_amdgcn_exp2f(ex.y);
-    const f32x2 q = pl * t * e;
-    f32x2 pos = a * bc2(k.cb);
-    pos.x = __builtin_fmaxf(pos.x, 0.f); pos.y = __builtin_fmaxf(pos.y, 0.f);
-    f32x2 g = fma2(av * bc2(k.ca), q, pos);
-    g.x = __builtin_fminf(g.x, 65504.f); g.y = __builtin_fminf(g.y, 65504.f);
-    const h2 h = __builtin_convertvector(g, h2);
-    const f32x2 back = __builtin_convertvector(h, f32x2);
-    const h2 l = __builtin_convertvector(g - back, h2);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
+#ifdef ACX_FSLAB_STAMP      // diagnostic build (tools/mlp_split_lab.hip): cycle shares of a chunk iteration
+__device__ unsigned long long acx_fs_stamps[8];
+#define ACX_FSTAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ACX_FSTAMP(var)
+#endif
 
 template <int C>
 struct FusedSCfg {
@@ -66,7 +51,9 @@ struct FusedSCfg {
     static constexpr int kRowChunks = C / 4;                 // 16-B chunks per W1c row
     static constexpr int kSteps = C / 16;                    // k-steps of phase 1
     static constexpr int kUnits = 2 * (C / 32);              // (out tile, k-step) units of phase 2
-    static constexpr size_t kLdsBytes = 4 * (size_t)kHalfBytes + 4 * C * 4;
+    static constexpr int kLead = 2;                          // iterations a weight image is requested ahead of use
+    static constexpr int kRing = kLead + 1;
+    static constexpr size_t kLdsBytes = 2 * kRing * (size_t)kHalfBytes + 4 * C * 4;
     __device__ static int swz1(int row) { return (C == 96) ? ((row >> 1) & 7) : (row & 15); }
 };
 
@@ -76,14 +63,20 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
     const float* __restrict__ b1, const float* __restrict__ b2, long long M, float sinv1, float sinv2) {
     using Cfg = FusedSCfg<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* w1buf = smem;                                                  // [2][kHalfBytes]  rows = hidden
-    char* w2buf = smem + 2 * Cfg::kHalfBytes;                            // [2][kHalfBytes]  rows = out channel
-    float* b1s = reinterpret_cast<float*>(smem + 4 * Cfg::kHalfBytes);   // [4C], pre-divided by sinv1
+    char* w1buf = smem;                                                  // [kRing][kHalfBytes]  rows = hidden
+    char* w2buf = smem + Cfg::kRing * Cfg::kHalfBytes;                   // [kRing][kHalfBytes]  rows = out channel
+    float* b1s = reinterpret_cast<float*>(smem + 2 * Cfg::kRing * Cfg::kHalfBytes);   // [4C], pre-divided by sinv1
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
+#ifdef ACX_FSLAB_STAMP
+    unsigned long long ts_begin = 0, ts_loop = 0, ts_end = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, sh[3] = {0, 0, 0};
+    unsigned long long rt_begin = 0, rt_end = 0;       // s_memrealtime: constant 100 MHz
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_begin) :: "memory");
+    ACX_FSTAMP(ts_begin)
+#endif
     const long long pix0 = (long long)blockIdx.x * Cfg::kPix + wave * 32;
     long long mrow = pix0 + l31;
     const bool valid = mrow < M;
@@ -98,6 +91,14 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
         const int r2 = idx >> 3, p2 = idx & 7;
         src2[k] = Cfg::kHalfBytes + (r2 * 8 + (p2 ^ ((r2 >> 1) & 7))) * 16;
     }
+#ifdef ACX_FSLAB_NO_DMA
+#define ACX_DMA(srcv, j, dstbase)
+#define ACX_DMA1(srcv, k, j, dstbase)
+#else
+#define ACX_DMA1(srcv, k, j, dstbase)                                                                           \
+        __builtin_amdgcn_global_load_lds(                                                                       \
+            (const __attribute__((address_space(1))) void*)(wpack + (long long)(j) * (2 * Cfg::kHalfBytes) + srcv[k]), \
+            (__attribute__((address_space(3))) void*)((dstbase) + (wave * Cfg::kPieces + (k)) * 1024), 16, 0, 0);
 #define ACX_DMA(srcv, j, dstbase)                                                                               \
     {                                                                                                           \
         const char* cb = wpack + (long long)(j) * (2 * Cfg::kHalfBytes);                                        \
@@ -106,9 +107,12 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
                 (const __attribute__((address_space(1))) void*)(cb + srcv[k]),                                  \
                 (__attribute__((address_space(3))) void*)((dstbase) + (wave * Cfg::kPieces + k) * 1024), 16, 0, 0); \
     }
-    ACX_DMA(src1, 0, w1buf);
-    ACX_DMA(src2, 0, w2buf);
-    ACX_DMA(src1, 1, w1buf + Cfg::kHalfBytes);
+#endif
+    constexpr int n = Cfg::kChunks, L = Cfg::kLead, R = Cfg::kRing;
+#pragma unroll
+    for (int c0 = 0; c0 < R; ++c0) ACX_DMA(src1, c0, w1buf + (c0 % R) * Cfg::kHalfBytes);     // chunks R..1+L follow the prologue
+#pragma unroll
+    for (int c0 = 0; c0 < L; ++c0) ACX_DMA(src2, c0, w2buf + (c0 % R) * Cfg::kHalfBytes);
     {
         const float b1scale = 1.0f / sinv1;             // a power of two
         for (int i = tid; i < 4 * C; i += Cfg::kThreads) b1s[i] = b1[i] * b1scale;
@@ -121,8 +125,12 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
         const float* yp = y + mrow * C + 8 * hh;
 #pragma unroll
         for (int s = 0; s < Cfg::kSteps; ++s) {
+#ifdef ACX_FSLAB_NO_IO       // diagnostic: no activation traffic (one load keeps the dependence)
+            const float4 v0 = *reinterpret_cast<const float4*>(y + 4 * (lane & 7)), v1 = v0;
+#else
             const float4 v0 = *reinterpret_cast<const float4*>(yp + 16 * s);
             const float4 v1 = *reinterpret_cast<const float4*>(yp + 16 * s + 4);
+#endif
             a[8 * s + 0] = v0.x; a[8 * s + 1] = v0.y; a[8 * s + 2] = v0.z; a[8 * s + 3] = v0.w;
             a[8 * s + 4] = v1.x; a[8 * s + 5] = v1.y; a[8 * s + 6] = v1.z; a[8 * s + 7] = v1.w;
         }
@@ -171,84 +179,192 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
     gk.cb = sinv1 * kSplitHiddenScale;
 
 #define ACX_H8(v_) __builtin_bit_cast(h8, v_)
-#define ACX_PHASE1(Xv, j, w1p)                                                                                  \
-    {                                                                                                           \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j) + 8 * q + 4 * hh);                  \
-            Xv[4 * q + 0] = bq[0]; Xv[4 * q + 1] = bq[1]; Xv[4 * q + 2] = bq[2]; Xv[4 * q + 3] = bq[3];         \
-        }                                                                                                       \
-        _Pragma("unroll") for (int s = 0; s < Cfg::kSteps; ++s) {                                               \
-            const f32x4 ah = *reinterpret_cast<const f32x4*>((w1p) + w1row + (((2 * (2 * s + hh)) ^ sw1) << 4));     \
-            const f32x4 al = *reinterpret_cast<const f32x4*>((w1p) + w1row + (((2 * (2 * s + hh) + 1) ^ sw1) << 4)); \
-            Xv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al), ACX_H8(acth[s]), Xv, 0, 0, 0);              \
-            Xv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah), ACX_H8(actl[s]), Xv, 0, 0, 0);              \
-            Xv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah), ACX_H8(acth[s]), Xv, 0, 0, 0);              \
-        }                                                                                                       \
-    }
-    __syncthreads();      // W1c(0), W1c(1), W2c(0) landed (hipcc drains the LDS-DMA before the barrier); b1s visible
-    f32x16 X;
-    ACX_PHASE1(X, 0, w1buf)
-    __syncthreads();      // every wave is done with W1 ring slot 0 before iteration 0 refills it
-
-    for (int j = 0; j < Cfg::kChunks; ++j) {
-        if (j + 2 < Cfg::kChunks) ACX_DMA(src1, j + 2, w1buf + (j & 1) * Cfg::kHalfBytes);
-        if (j + 1 < Cfg::kChunks) ACX_DMA(src2, j + 1, w2buf + ((j + 1) & 1) * Cfg::kHalfBytes);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 Xn;
-        f32x4 gh[2], gl[2];                 // G(j) as B-operand halves for the two k-steps of phase 2
-        {
-            unsigned uh[8], ul[8];
-            if (j + 1 < Cfg::kChunks) {
-                const char* w1p = w1buf + ((j + 1) & 1) * Cfg::kHalfBytes;
-                ACX_PHASE1(Xn, j + 1, w1p)
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Xn[r] = 0.f;
-            }
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                f32x2 a2;
-                a2.x = X[2 * p]; a2.y = X[2 * p + 1];
-                gelu_split2(a2, gk, uh[p], ul[p]);
-            }
-            gh[0] = __builtin_bit_cast(f32x4, uint4{uh[0], uh[1], uh[2], uh[3]});
-            gh[1] = __builtin_bit_cast(f32x4, uint4{uh[4], uh[5], uh[6], uh[7]});
-            gl[0] = __builtin_bit_cast(f32x4, uint4{ul[0], ul[1], ul[2], ul[3]});
-            gl[1] = __builtin_bit_cast(f32x4, uint4{ul[4], ul[5], ul[6], ul[7]});
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const char* w2p = w2buf + (j & 1) * Cfg::kHalfBytes + w2row;
-        // unit i = (tile t = i >> 1, k-step s' = i & 1): fragments of block b = 2s' + hh, hi chunk 2b, lo chunk 2b+1.
-        // Fragments are double-buffered in two NAMED register pairs (see mlp_fused.hip).
-#define ACX_W2_RD(i_, pl_) (*reinterpret_cast<const f32x4*>(w2p + ((i_) >> 1) * 4096 + (((2 * (2 * ((i_) & 1) + hh) + (pl_)) ^ sw2) << 4)))
-#define ACX_W2_MFMA(i_, ah_, al_)                                                                               \
+#define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
+    // phase-1 unit = k-step s_: two fragment reads, three MFMAs chained on Xacc
+#ifdef ACX_FSLAB_NO_LDSREAD   // diagnostic: fragments come from registers, no ds_read in the loop
+#define ACX_W1_RD(w1p_, s_, pl_) (acth[(s_) % Cfg::kSteps])
+#else
+#define ACX_W1_RD(w1p_, s_, pl_) (*reinterpret_cast<const f32x4*>((w1p_) + w1row + (((2 * (2 * (s_) + hh) + (pl_)) ^ sw1) << 4)))
+#endif
+#define ACX_P1_MFMA(Xacc, s_, ah_, al_)                                                                         \
+        Xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[s_]), Xacc, 0, 0, 0);            \
+        Xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(actl[s_]), Xacc, 0, 0, 0);            \
+        Xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(acth[s_]), Xacc, 0, 0, 0);
+    // phase-2 unit i = (tile t = i >> 1, k-step s' = i & 1): fragments of block b = 2s' + hh, hi chunk 2b, lo chunk 2b+1
+#ifdef ACX_FSLAB_NO_LDSREAD
+#define ACX_W2_RD(w2p_, i_, pl_) (actl[(i_) % Cfg::kSteps])
+#else
+#define ACX_W2_RD(w2p_, i_, pl_) (*reinterpret_cast<const f32x4*>((w2p_) + ((i_) >> 1) * 4096 + (((2 * (2 * ((i_) & 1) + hh) + (pl_)) ^ sw2) << 4)))
+#endif
+#define ACX_P2_MFMA(i_, ah_, al_)                                                                               \
         acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
         acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gl[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
         acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0);
-        f32x4 a0h = ACX_W2_RD(0, 0), a0l = ACX_W2_RD(0, 1), a1h, a1l;
-#pragma unroll
-        for (int i = 0; i < Cfg::kUnits; i += 2) {
-            a1h = ACX_W2_RD(i + 1, 0); a1l = ACX_W2_RD(i + 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            ACX_W2_MFMA(i, a0h, a0l)
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" :: "v"(a1h)); asm volatile("" :: "v"(a1l));
-            if (i + 2 < Cfg::kUnits) { a0h = ACX_W2_RD(i + 2, 0); a0l = ACX_W2_RD(i + 2, 1); }
-            __builtin_amdgcn_sched_barrier(0);
-            ACX_W2_MFMA(i + 1, a1h, a1l)
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 2 < Cfg::kUnits) { asm volatile("" :: "v"(a0h)); asm volatile("" :: "v"(a0l)); }
+#define ACX_TOUCH2(h_, l_) { asm volatile("" :: "v"(h_)); asm volatile("" :: "v"(l_)); }
+#define ACX_BIAS_INIT(Xacc, j_)                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j_) + 8 * q + 4 * hh);                 \
+            Xacc[4 * q + 0] = bq[0]; Xacc[4 * q + 1] = bq[1]; Xacc[4 * q + 2] = bq[2]; Xacc[4 * q + 3] = bq[3]; \
         }
-#undef ACX_W2_RD
-#undef ACX_W2_MFMA
-        X = Xn;
-        __syncthreads();
+    // GELU pieces [first, first + count) of the 24 that turn Xv into the packed halves uh/ul
+#define ACX_PIECES(first_, count_)                                                                              \
+        _Pragma("unroll") for (int pc_ = (first_); pc_ < (first_) + (count_); ++pc_) {                          \
+            const int pr_ = pc_ / 3, sub_ = pc_ - 3 * pr_;                                                      \
+            f32x2 a2_;                                                                                          \
+            a2_.x = Xv[2 * pr_]; a2_.y = Xv[2 * pr_ + 1];                                                       \
+            if (sub_ == 0) gelu_piece1(a2_, gk, s_av[pr_], s_t[pr_], s_e[pr_]);                                 \
+            else if (sub_ == 1) gelu_piece2(a2_, s_av[pr_], s_t[pr_], s_e[pr_], gk, s_g[pr_]);                  \
+            else gelu_piece3(s_g[pr_], uh[pr_], ul[pr_]);                                                       \
+        }
+#define ACX_PACK_G(dh_, dl_)                                                                                    \
+        dh_[0] = __builtin_bit_cast(f32x4, uint4{uh[0], uh[1], uh[2], uh[3]});                                  \
+        dh_[1] = __builtin_bit_cast(f32x4, uint4{uh[4], uh[5], uh[6], uh[7]});                                  \
+        dl_[0] = __builtin_bit_cast(f32x4, uint4{ul[0], ul[1], ul[2], ul[3]});                                  \
+        dl_[1] = __builtin_bit_cast(f32x4, uint4{ul[4], ul[5], ul[6], ul[7]});
+
+    __syncthreads();      // W1c(0..1+L), W2c(0..L-1) landed (hipcc drains the LDS-DMA before the barrier); b1s visible
+    f32x16 Xv, Xnn;       // Xv: pre-activation of chunk j+1 (GELU input of iteration j); Xnn: chunk j+2, accumulating
+    f32x4 gh[2], gl[2];   // G(j): B operand of phase 2, two k-steps, hi / lo halves
+    f32x2 s_av[8], s_t[8], s_e[8], s_g[8];
+    unsigned uh[8], ul[8];
+    {   // prologue: X(0) -> G(0), X(1) -> Xv; nothing to overlap with yet
+        ACX_BIAS_INIT(Xv, 0)
+#pragma unroll
+        for (int s = 0; s < Cfg::kSteps; ++s) {
+            const f32x4 ah = ACX_W1_RD(w1buf, s, 0), al = ACX_W1_RD(w1buf, s, 1);
+            ACX_P1_MFMA(Xv, s, ah, al)
+        }
+        ACX_PIECES(0, 24)
+        ACX_PACK_G(gh, gl)
+        ACX_BIAS_INIT(Xv, 1)
+#pragma unroll
+        for (int s = 0; s < Cfg::kSteps; ++s) {
+            const f32x4 ah = ACX_W1_RD(w1buf + Cfg::kHalfBytes, s, 0), al = ACX_W1_RD(w1buf + Cfg::kHalfBytes, s, 1);
+            ACX_P1_MFMA(Xv, s, ah, al)
+        }
     }
+    __syncthreads();      // every wave is done with W1 ring slots 0 and 1 before they are refilled
+#pragma unroll
+    for (int c0 = R; c0 < 2 + L; ++c0) ACX_DMA(src1, c0, w1buf + (c0 % R) * Cfg::kHalfBytes);
+
+    ACX_FSTAMP(ts_loop)
+    auto body = [&](auto has_a, auto has_v, const int j) __attribute__((always_inline)) {
+        constexpr bool HA = decltype(has_a)::value, HV = decltype(has_v)::value;
+        constexpr int kRegions = (HA ? Cfg::kSteps : 0) + Cfg::kUnits;
+        constexpr int kPer = HV ? 24 / kRegions : 0;           // GELU pieces per unit (24 divides evenly: 12, 24 or 6 units)
+        static_assert(!HV || kPer * kRegions == 24, "GELU pieces must divide over the units");
+        // this iteration's DMA pieces (W1c(j+2+L) then W2c(j+L)) are threaded through the units, one every
+        // kRegions / (2 kPieces) units: issued in a burst each piece costs 100-185 cycles of issue
+        constexpr int kDmaStride = kRegions / (2 * Cfg::kPieces);
+        static_assert(kDmaStride * 2 * Cfg::kPieces == kRegions, "DMA pieces must divide over the units");
+        const bool dma1 = j + 2 + L < n, dma2 = j + L < n;
+        char* const d1 = w1buf + ((j + 2 + L) % R) * Cfg::kHalfBytes;
+        char* const d2 = w2buf + ((j + L) % R) * Cfg::kHalfBytes;
+#define ACX_DMA_AT(region_)                                                                                     \
+        if ((region_) % kDmaStride == 0) {                                                                      \
+            constexpr int q_ = 0;                                                                               \
+            const int qq_ = (region_) / kDmaStride + q_;                                                        \
+            if (qq_ < Cfg::kPieces) { if (dma1) { ACX_DMA1(src1, qq_, j + 2 + L, d1) } }                        \
+            else if (dma2) { ACX_DMA1(src2, qq_ - Cfg::kPieces, j + L, d2) }                                    \
+        }
+        ACX_FENCE
+        ACX_FSTAMP(t0)
+        int region = 0;
+        if constexpr (HA) {
+            const char* w1p = w1buf + ((j + 2) % R) * Cfg::kHalfBytes;
+            ACX_BIAS_INIT(Xnn, j + 2)
+            f32x4 a0h = ACX_W1_RD(w1p, 0, 0), a0l = ACX_W1_RD(w1p, 0, 1), a1h, a1l;
+#pragma unroll
+            for (int s = 0; s < Cfg::kSteps; s += 2) {
+                a1h = ACX_W1_RD(w1p, s + 1, 0); a1l = ACX_W1_RD(w1p, s + 1, 1);
+                ACX_FENCE
+                ACX_P1_MFMA(Xnn, s, a0h, a0l)
+                ACX_DMA_AT(s)
+                ACX_PIECES(kPer * (s), kPer)
+                ACX_FENCE
+                ACX_TOUCH2(a1h, a1l)
+                if (s + 2 < Cfg::kSteps) { a0h = ACX_W1_RD(w1p, s + 2, 0); a0l = ACX_W1_RD(w1p, s + 2, 1); }
+                ACX_FENCE
+                ACX_P1_MFMA(Xnn, s + 1, a1h, a1l)
+                ACX_DMA_AT(s + 1)
+                ACX_PIECES(kPer * (s + 1), kPer)
+                ACX_FENCE
+                if (s + 2 < Cfg::kSteps) ACX_TOUCH2(a0h, a0l)
+            }
+            region = Cfg::kSteps;
+        }
+        ACX_FSTAMP(t1)
+        {
+            const char* w2p = w2buf + (j % R) * Cfg::kHalfBytes + w2row;
+            const int r0 = HA ? Cfg::kSteps : 0;
+            f32x4 a0h = ACX_W2_RD(w2p, 0, 0), a0l = ACX_W2_RD(w2p, 0, 1), a1h, a1l;
+#pragma unroll
+            for (int i = 0; i < Cfg::kUnits; i += 2) {
+                a1h = ACX_W2_RD(w2p, i + 1, 0); a1l = ACX_W2_RD(w2p, i + 1, 1);
+                ACX_FENCE
+                ACX_P2_MFMA(i, a0h, a0l)
+                ACX_DMA_AT(r0 + i)
+                ACX_PIECES(kPer * (r0 + i), kPer)
+                ACX_FENCE
+                ACX_TOUCH2(a1h, a1l)
+                if (i + 2 < Cfg::kUnits) { a0h = ACX_W2_RD(w2p, i + 2, 0); a0l = ACX_W2_RD(w2p, i + 2, 1); }
+                ACX_FENCE
+                ACX_P2_MFMA(i + 1, a1h, a1l)
+                ACX_DMA_AT(r0 + i + 1)
+                ACX_PIECES(kPer * (r0 + i + 1), kPer)
+                ACX_FENCE
+                if (i + 2 < Cfg::kUnits) ACX_TOUCH2(a0h, a0l)
+            }
+        }
+#undef ACX_DMA_AT
+        (void)region;
+        if constexpr (HV) { ACX_PACK_G(gh, gl) }
+        if constexpr (HA) { Xv = Xnn; }
+        ACX_FSTAMP(t2)
+        ACX_FENCE
+        // images requested this iteration may stay in flight; everything older must have landed
+        if (L == 2 && j + 2 + L < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * Cfg::kPieces) : "memory");
+        else if (L == 2 && j + L < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::kPieces) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef ACX_FSLAB_NO_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+        ACX_FENCE
+        ACX_FSTAMP(t3)
+#ifdef ACX_FSLAB_STAMP
+        sh[0] += t1 - t0; sh[1] += t2 - t1; sh[2] += t3 - t2;
+#endif
+    };
+#ifdef ACX_FSLAB_NO_LOOP     // diagnostic: prologue + epilogue only
+    body(std::false_type{}, std::false_type{}, n - 1);
+#else
+    for (int j = 0; j + 2 < n; ++j) body(std::true_type{}, std::true_type{}, j);
+    body(std::false_type{}, std::true_type{}, n - 2);
+    body(std::false_type{}, std::false_type{}, n - 1);
+#endif
+    ACX_FSTAMP(ts_end)
 #undef ACX_DMA
-#undef ACX_PHASE1
+#undef ACX_DMA1
 #undef ACX_H8
+#undef ACX_FENCE
+#undef ACX_W1_RD
+#undef ACX_P1_MFMA
+#undef ACX_W2_RD
+#undef ACX_P2_MFMA
+#undef ACX_TOUCH2
+#undef ACX_BIAS_INIT
+#undef ACX_PIECES
+#undef ACX_PACK_G
 
     // ---- epilogue: lane (px, hh), tile t, q: channels 32t + 8q + 4hh .. +3  ->  x = x + out + b2 ---------
+#ifdef ACX_FSLAB_NO_IO
+    {
+        float t = 0.f;
+        _Pragma("unroll") for (int tt = 0; tt < C / 32; ++tt) _Pragma("unroll") for (int r = 0; r < 16; ++r) t += acc[tt][r];
+        if (t == 12345.678f) x[tid] = t;
+        return;
+    }
+#endif
     if (valid) {
         float* xp = x + mrow * C + 4 * hh;
 #pragma unroll
@@ -266,6 +382,20 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
             }
         }
     }
+#ifdef ACX_FSLAB_STAMP
+    {
+        unsigned long long ts_fin = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ACX_FSTAMP(ts_fin)
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_end) :: "memory");
+        if (lane == 0) atomicAdd(&acx_fs_stamps[7], (rt_end - rt_begin) * 1000ULL + 0 * (ts_fin - ts_begin));
+        if (lane == 0) {
+            atomicAdd(&acx_fs_stamps[0], sh[0]); atomicAdd(&acx_fs_stamps[1], sh[1]); atomicAdd(&acx_fs_stamps[2], sh[2]);
+            atomicAdd(&acx_fs_stamps[3], ts_loop - ts_begin); atomicAdd(&acx_fs_stamps[4], ts_end - ts_loop);
+            atomicAdd(&acx_fs_stamps[5], ts_fin - ts_end); atomicAdd(&acx_fs_stamps[6], 1ULL);
+        }
+    }
+#endif
 }
 
 template <int C>
