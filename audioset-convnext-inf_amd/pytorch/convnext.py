@@ -128,7 +128,11 @@ class ConvNeXt(nn.Module):
         self.head_audioset.bias.data.mul_(head_init_scale)
 
         self._ctx = {}          # device index -> (_ffi.Context, weight signature)
-        self.precision = "fp32" # set_precision("bf16"): bf16 MFMA contractions (BASELINE configs[2])
+        # arithmetic of the dense contractions (include/acx.h, enum acx_precision).  "fp32_split" and "fp32" are both
+        # fp32-grade (same parity tests, same tolerances); split is the fast one.  ACX_PRECISION overrides the default.
+        self.precision = os.environ.get("ACX_PRECISION", "fp32_split")
+        if self.precision not in _ffi.PRECISIONS:
+            raise ValueError("ACX_PRECISION must be one of %s" % sorted(_ffi.PRECISIONS))
         self._ws = {}           # device index -> workspace tensor
 
     def _init_weights(self, m):
@@ -141,9 +145,11 @@ class ConvNeXt(nn.Module):
         return (self.precision,) + tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
 
     def set_precision(self, precision):
-        """"fp32": the reference's arithmetic (default; 1e-3 parity).  "bf16": pointwise / downsample contractions
-        with bf16 operands and fp32 accumulation; LayerNorm, residual stream, depthwise conv, frontend and head
-        stay fp32.  The reference has no such switch (closest: torch autocast around its nn.Linear layers)."""
+        """"fp32_split" (default): fp32 GEMM operands carried as fp16 hi + fp16 lo, three fp16 MFMAs per product, fp32
+        accumulate -- fp32-grade (1e-3 parity), 16/3 of the f32-MFMA rate.  "fp32": v_mfma_f32_32x32x2_f32 on the
+        fp32 operands themselves.  "bf16": pointwise / downsample contractions with bf16 operands and fp32
+        accumulation (NOT within the 1e-3 bar); LayerNorm, residual stream, depthwise conv, frontend and head stay
+        fp32 in every mode.  The reference has no such switch (closest: torch autocast around its nn.Linear layers)."""
         if precision not in _ffi.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_ffi.PRECISIONS))
         self.precision = precision

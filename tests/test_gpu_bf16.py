@@ -151,7 +151,7 @@ def test_precision_switch_rebuilds_context(synth_sd):
     m = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
                       use_speed_perturb=False)
     m.load_state_dict(synth_sd)
-    m = m.to("cuda").eval()
+    m = m.to("cuda").eval().set_precision("fp32")
     from audioset_convnext_inf_amd import synth
     wav = synth.synth_waveforms(2, 32000, seed=9).cuda()
     a = m(wav)["clipwise_logits"].clone()

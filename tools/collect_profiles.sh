@@ -1,12 +1,14 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): bench line + rocprofv3 kernel stats + PMC passes -> gpurun_out/final/
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
-cd $R && python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
+# usage: collect_profiles.sh [precision]   (fp32_split | fp32 | bf16)
+PREC=${1:-fp32_split}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$PREC; mkdir -p $O
+cd $R && python bench.py --precision $PREC --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile > $O/stats.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 $R/tools/prof_step.py > $O/pmc_sq.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/tools/prof_step.py > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/tools/prof_step.py > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --precision $PREC --steps 20 --warmup 3 --no-cpu-baseline --no-profile > $O/stats.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 $R/tools/prof_step.py --precision $PREC > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/tools/prof_step.py --precision $PREC > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/tools/prof_step.py --precision $PREC > $O/pmc_write.log 2>&1
 cd $R && python tools/pmc_table.py $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/pmc_per_kernel.csv $O/traffic.json > $O/pmc_table.log 2>&1
 tail -3 $O/pmc_table.log; cat $O/bench.json | cut -c1-400

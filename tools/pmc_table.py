@@ -21,7 +21,7 @@ def cls(name):
                    ("rowstats", "rowstats"), ("pool_head", "poolhead"), ("nhwc_to_nchw", "transpose")):
         if key in name:
             return c
-    if "gemm_f32_kernel" in name:
+    if "gemm_f32_kernel" in name or "gemm_split_kernel" in name or "gemm_bf16_kernel" in name:
         t = name.split("<")[1].split(">")[0].replace(" ", "").split(",")
         return {"1": "pw1", "2": "pw2"}.get(t[4], "downsample")
     return None
@@ -29,7 +29,7 @@ def cls(name):
 sq, fe, wr = load(sys.argv[1]), load(sys.argv[2]), load(sys.argv[3])
 agg = collections.OrderedDict()
 with open(sys.argv[4], "w") as out:
-    out.write("# one forward, B=64 x 10 s, fp32 (tools/prof_step.py); three separate rocprofv3 --pmc passes.\n")
+    out.write("# one forward, B=64 x 10 s (tools/prof_step.py, default precision, one stream); three separate rocprofv3 --pmc passes.\n")
     out.write("# fetch_MB_x2 = 2 * FETCH_SIZE (gfx950 reports half the bytes of 16 B/lane streaming reads); write_MB = WRITE_SIZE.\n")
     out.write("class,kernel,grid,dur_us,clock_GHz,waves_per_SIMD,wait_any,wait_inst_any,valu_active,mfma_util,lds_bank_conflict_per_cu_cycle,fetch_MB_x2,write_MB\n")
     for x, y, z in zip(sq, fe, wr):
@@ -50,5 +50,5 @@ summary = {c: {"launches_per_step": a["launches"], "hbm_traffic_bytes_per_launch
                "fetch_bytes_per_launch_x2": a["fetch_MB_x2"] * 1e6 / a["launches"], "write_bytes_per_launch": a["write_MB"] * 1e6 / a["launches"],
                "mfma_util_cycles": a["mfma_busy"] / a["simd_cycles"]} for c, a in agg.items()}
 json.dump({"source": "rocprofv3 --pmc, 3 passes: SQ_*+GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE; FETCH_SIZE x2 (gfx950 correction)",
-           "workload": "one forward, B=64, 10 s @ 32 kHz, fp32", "classes": summary}, open(sys.argv[5], "w"), indent=1)
+           "workload": "one forward, B=64, 10 s @ 32 kHz (tools/prof_step.py, default precision, one stream)", "classes": summary}, open(sys.argv[5], "w"), indent=1)
 print(json.dumps(summary, indent=1))
