@@ -46,11 +46,13 @@ __device__ __forceinline__ void lds_dma16_s(const char* gsrc, char* lds_wave_bas
 
 // EPI: 0 bias -> fp32, 1 bias + GELU -> S16 (scaled by kHiddenScale), 2 bias + residual -> fp32
 template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
-__global__ __launch_bounds__(256) void gemm_split_kernel(GemmSParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p) {
     constexpr int TM = kBM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
+    constexpr int NW = WM * WN;                                           // waves per workgroup (4 or 8)
     constexpr int A_TILE = kBM * kSRowBytes, B_TILE = BN * kSRowBytes;
-    constexpr int A_DMA = kBM / 32, B_DMA = BN / 32;
+    constexpr int A_DMA = kBM / (8 * NW), B_DMA = BN / (8 * NW);          // 1-KB pieces per wave per tile
+    static_assert(A_DMA * 8 * NW == kBM && B_DMA * 8 * NW == BN, "tile rows must split into 8-row pieces per wave");
     constexpr bool SWAP = (EPI == 1);      // D = (W A^T): lane = m, registers = 4 consecutive n -> packed S16 stores
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
@@ -87,7 +89,11 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSParams p) {
             const long long b = t / p.Ho;
             a_src[i] = p.A + (((b * p.H + 2 * ho) * p.W + 2 * wo) * p.C) * 4 + 16 * chunk;
         } else {
+#ifdef ACX_SLAB_A_RESIDENT     // diagnostic: the A stream comes from L2 (256 distinct rows), not from HBM
+            a_src[i] = p.A + (m & 255) * p.K * 4 + 16 * chunk;
+#else
             a_src[i] = p.A + m * p.K * 4 + 16 * chunk;
+#endif
         }
     }
     const char* b_src[B_DMA];
@@ -332,7 +338,7 @@ static int launch_s_cfg(const GemmSParams& p0, hipStream_t s) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(p);
+    gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(64 * WM * WN), lds, s>>>(p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
@@ -345,6 +351,12 @@ static int launch_s_bn(const GemmSParams& p, hipStream_t s) {
     if (p.N % 256 == 0 && p.K >= 384) return launch_s_cfg<256, 256, 2, 2, EPI, GATHER>(p, s);
     if (p.N % 128 == 0 && p.K >= 384) return launch_s_cfg<256, 128, 2, 2, EPI, GATHER>(p, s);
 #endif
+#ifdef ACX_SPLIT_8W
+    if (p.N % 128 == 0 && p.K >= 192) return launch_s_cfg<256, 128, 4, 2, EPI, GATHER>(p, s);
+#endif
+    // pwconv1 (N = 4C >= 1536 here): 128 x 192 tiles -- 15 % fewer operand bytes per flop through the LDS-DMA path
+    // and 36 instead of 24 MFMAs per barrier (tools/split_lab: s2.pw1 264 vs 277 us, s3.pw1 200 vs 211)
+    if (EPI == 1 && p.N % 192 == 0 && p.N >= 768 && !small) return launch_s_cfg<128, 192, 2, 2, EPI, GATHER>(p, s);
     if (p.N % 128 == 0) {
         if (small) return launch_s_cfg<64, 128, 2, 2, EPI, GATHER>(p, s);
         return launch_s_cfg<128, 128, 2, 2, EPI, GATHER>(p, s);
