@@ -53,7 +53,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
     constexpr int A_TILE = kBM * kSRowBytes, B_TILE = BN * kSRowBytes;
     constexpr int A_DMA = kBM / (8 * NW), B_DMA = BN / (8 * NW);          // 1-KB pieces per wave per tile
     static_assert(A_DMA * 8 * NW == kBM && B_DMA * 8 * NW == BN, "tile rows must split into 8-row pieces per wave");
-    constexpr bool SWAP = (EPI == 1);      // D = (W A^T): lane = m, registers = 4 consecutive n -> packed S16 stores
+    // D = (W A^T): lane = row m, registers = 4 consecutive n -> 16-B accesses per lane in every epilogue
+    // (the un-swapped form, 4-B accesses with n on the lanes, spent 73 of 289 us in pwconv2's read-modify-write)
+    constexpr bool SWAP = true;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
     char* Bs = smem + 2 * A_TILE;
@@ -186,6 +188,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         _Pragma("unroll") for (int j = 0; j < TN; ++j) { asm volatile("" :: "v"(F##bh[j])); asm volatile("" :: "v"(F##bl[j])); } \
     }
 
+#ifdef ACX_SLAB_NO_BARRIER     // diagnostic: k-loop without its barrier (wrong results)
+#define ACX_LOOP_BARRIER
+#else
+#define ACX_LOOP_BARRIER __syncthreads();
+#endif
     const int nk = p.K / kSBK;
     // prologue: tiles 0 and 1 in flight, fragments of tile 0 in registers
     ACX_DMA_TILE(a_koff(0), 0LL, 0)
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         ACX_MFMA_STEP(F0)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(F1)
-        __syncthreads();
+        ACX_LOOP_BARRIER
         ACX_READ_FRAGS(F0, abn, bbn, 0)
         __builtin_amdgcn_sched_barrier(0);
         ACX_MFMA_STEP_DMA(F1, ka, (long long)k2 * 4, kt & 1)
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         ACX_MFMA_STEP(F0)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(F1)
-        __syncthreads();
+        ACX_LOOP_BARRIER
         ACX_READ_FRAGS(F0, abn, bbn, 0)
         __builtin_amdgcn_sched_barrier(0);
         ACX_MFMA_STEP(F1)
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
     }
 #endif
     const float sinv = p.sinv;
-    if (SWAP) {
+    if (EPI == 1) {
         GeluConsts gk;          // GELU of v = a * sinv, result x kSplitHiddenScale (see split_math.h)
         gk.ps = 0.3275911f * 0.70710678f * sinv;
         gk.cs = -0.72134752f * sinv * sinv;
@@ -297,27 +304,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
             }
         }
     } else {
-        // ---- fp32 epilogue: D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ------------
+        // ---- fp32 epilogue, same layout: lane (l31, hh) owns row m, columns nb + 8q + 4hh .. +3 of tile (i, j) ------
         float* outf = reinterpret_cast<float*>(p.out);
-        const bool full = m0 + kBM <= p.M;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const long long mb = m0 + (wm * TM + i) * 32 + 4 * hh;
+            const long long m = m0 + (wm * TM + i) * 32 + l31;
+            const bool ok = m < p.M;
+            const long long row = (ok ? m : 0) * p.N;
+            f32x4 rv[TN][4];
+            if (EPI == 2) {       // all residual loads of the row tile in flight before the first store
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        rv[j][q] = *reinterpret_cast<const f32x4*>(p.resid + row + n0 + (wn * TN + j) * 32 + 8 * q + 4 * hh);
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + (wn * TN + j) * 32 + l31;
-                const float bn = p.bias[n];
-                float* op = outf + mb * p.N + n;
-                const float* rp = (EPI == 2) ? p.resid + mb * p.N + n : nullptr;
+                const int nb = n0 + (wn * TN + j) * 32;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    if (full || mb + dr < p.M) {
-                        const long long off = (long long)dr * p.N;
-                        float v = fmaf(acc[i][j][r], sinv, bn);
-                        if (EPI == 2) v += rp[off];
-                        op[off] = v;
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * q + 4 * hh);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaf(acc[i][j][4 * q + e], sinv, b4[e]);
+                        if (EPI == 2) v[e] += rv[j][q][e];
                     }
+                    if (ok) *reinterpret_cast<f32x4*>(outf + row + nb + 8 * q + 4 * hh) = v;
                 }
             }
         }
@@ -350,6 +364,9 @@ static int launch_s_bn(const GemmSParams& p, hipStream_t s) {
 #ifdef ACX_SPLIT_BIG
     if (p.N % 256 == 0 && p.K >= 384) return launch_s_cfg<256, 256, 2, 2, EPI, GATHER>(p, s);
     if (p.N % 128 == 0 && p.K >= 384) return launch_s_cfg<256, 128, 2, 2, EPI, GATHER>(p, s);
+#endif
+#ifdef ACX_SPLIT_SMALL
+    if (p.N % 128 == 0) return launch_s_cfg<64, 128, 2, 2, EPI, GATHER>(p, s);
 #endif
 #ifdef ACX_SPLIT_8W
     if (p.N % 128 == 0 && p.K >= 192) return launch_s_cfg<256, 128, 4, 2, EPI, GATHER>(p, s);
