@@ -17,7 +17,6 @@ constexpr int kDepths[4] = {3, 3, 9, 3};        // convnext.py:655
 constexpr int kDims[4] = {96, 192, 384, 768};   // convnext.py:656
 constexpr int kNFFT = 1024, kHop = 320, kBins = 513, kMels = 224;   // convnext.py:168-172
 constexpr int kClasses = ACX_NUM_CLASSES;
-constexpr int kHeadPad = 544;                   // 527 padded to a multiple of 32
 constexpr int kStemW = 56;                      // 224 mel bins / 4
 
 void set_error(const char* fmt, ...);

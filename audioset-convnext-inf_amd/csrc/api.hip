@@ -622,7 +622,10 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
     // Clips are independent: a large batch runs as two halves on two streams (fork/join with events, so the call
     // still looks like one unit of work on `stream` and stays graph-capturable).  Per-kernel event profiling
     // runs un-split to keep launch durations clean.
-    if (c->split_streams && !c->prof.on && B >= kSplitMinBatch) {
+    // Not in fp32_split arithmetic: a split GEMM running next to an FFT-type kernel of ANOTHER stream (our own log-mel
+    // kernel, rocFFT) perturbs that kernel's results on this platform -- reproduced, not yet explained
+    // (tools/canary/, DESIGN.md "Open issue") -- so that arithmetic keeps to one stream.
+    if (c->split_streams && c->precision != ACX_PREC_F32_SPLIT && !c->prof.on && B >= kSplitMinBatch) {
         const int B0 = (B + 1) / 2, B1 = B / 2;
         Plan p0, p1;
         ACX_TRY(make_plan(B0, L, &p0));
@@ -673,8 +676,11 @@ int acx_block_mlp(acx_ctx* c, int stage, int block, const float* y, const float*
     const BlockW& bw = c->blocks[stage][block];
     const int64_t M = (int64_t)B * H * Wd;
     if (c->precision == ACX_PREC_BF16) return run_mlp_bf16(c, bw, C, y, x, hidden, M, (hipStream_t)stream);
-    if (c->precision == ACX_PREC_F32_SPLIT) {      // y is left untouched: the S16 rows go to the tail of `hidden`... no room: use a copy
-        ACX_FAIL(ACX_ERR_UNSUPPORTED, "acx_block_mlp: split precision normalises y in place; call acx_block instead");
+    if (c->precision == ACX_PREC_F32_SPLIT) {
+        // stages 0-1 run the fused kernel (y is read only); the two-GEMM stages normalise y IN PLACE into S16 form,
+        // which this entry point's const y cannot offer: acx_block is the per-block entry point there
+        if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused_split(c, bw, C, y, x, M, (hipStream_t)stream);
+        ACX_FAIL(ACX_ERR_UNSUPPORTED, "acx_block_mlp: in fp32_split precision stage %d normalises y in place; call acx_block", stage);
     }
     if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused(c, bw, C, y, x, M, (hipStream_t)stream);
     GemmArgs g1{};

@@ -144,6 +144,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         }                                                                                              \
     }
 #define ACX_H8(x) __builtin_bit_cast(h8, x)
+#ifdef ACX_SLAB_NO_MFMA
+#define ACX_MFMA1(term, i, j, F) asm volatile("" :: "v"(F##ah[i]), "v"(F##bl[j]), "v"(F##al[i]), "v"(F##bh[j]));
+#elif defined(ACX_DBG_BF16_MFMA)     /* diagnostic: same kernel, bf16 opcode (numerically meaningless) */
+typedef __bf16 dbg_b8 __attribute__((ext_vector_type(8)));
+#define ACX_MFMA1(term, i, j, F)                                                                       \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbg_b8, (term) == 0 ? F##bl[j] : F##bh[j]),  \
+                                                            __builtin_bit_cast(dbg_b8, (term) == 1 ? F##al[i] : F##ah[i]), acc[i][j], 0, 0, 0);
+#elif defined(ACX_DBG_TWO_TERM)
+#define ACX_MFMA1(term, i, j, F)                                                                       \
+    if ((term) >= 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bh[j]), ACX_H8((term) == 1 ? F##al[i] : F##ah[i]), acc[i][j], 0, 0, 0); \
+    else asm volatile("" :: "v"(F##bl[j]));
+#elif defined(ACX_DBG_NOP_TERM)
+#define ACX_MFMA1(term, i, j, F)                                                                       \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8((term) == 0 ? F##bl[j] : F##bh[j]),     \
+                                                       ACX_H8((term) == 1 ? F##al[i] : F##ah[i]), acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_nop(7);
+#elif defined(ACX_DBG_ONE_TERM)
+#define ACX_MFMA1(term, i, j, F)                                                                       \
+    if ((term) == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bh[j]), ACX_H8(F##ah[i]), acc[i][j], 0, 0, 0); \
+    else asm volatile("" :: "v"(F##bl[j]), "v"(F##al[i]));
+#else
 #define ACX_MFMA1(term, i, j, F)     /* term 0: lo x hi, 1: hi x lo, 2: hi x hi */                      \
     if (SWAP) {                                                                                        \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8((term) == 0 ? F##bl[j] : F##bh[j]),  \
@@ -152,12 +173,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8((term) == 0 ? F##al[i] : F##ah[i]),  \
                                                            ACX_H8((term) == 1 ? F##bl[j] : F##bh[j]), acc[i][j], 0, 0, 0); \
     }
+#endif
     // term-major order: MFMAs on the same accumulator are TM*TN instructions apart
+#ifdef ACX_SLAB_SETPRIO
+#define ACX_PRIO_HI __builtin_amdgcn_s_setprio(3);
+#define ACX_PRIO_LO __builtin_amdgcn_s_setprio(0);
+#else
+#define ACX_PRIO_HI
+#define ACX_PRIO_LO
+#endif
 #define ACX_MFMA_STEP(F)                                                                               \
     {                                                                                                  \
+        ACX_PRIO_HI                                                                                    \
         _Pragma("unroll") for (int term = 0; term < 3; ++term)                                         \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) { ACX_MFMA1(term, i, j, F) }                    \
+        ACX_PRIO_LO                                                                                    \
     }
     // the same with the LDS-DMA pieces of a later tile threaded in, one piece in front of each MFMA
 #define ACX_MFMA_STEP_DMA(F, koffA, k0B, buf)                                                          \
@@ -222,7 +253,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         ACX_LOOP_BARRIER
         ACX_READ_FRAGS(F0, abn, bbn, 0)
         __builtin_amdgcn_sched_barrier(0);
+#ifdef ACX_GS_ONE_IN_FLIGHT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifdef ACX_GS_BURST
+        ACX_DMA_TILE(ka, (long long)k2 * 4, kt & 1)
+        ACX_MFMA_STEP(F1)
+#else
         ACX_MFMA_STEP_DMA(F1, ka, (long long)k2 * 4, kt & 1)
+#endif
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(F0)
         ACX_READ_FRAGS(F1, abn, bbn, 1)
@@ -373,7 +412,9 @@ static int launch_s_bn(const GemmSParams& p, hipStream_t s) {
 #endif
     // pwconv1 (N = 4C >= 1536 here): 128 x 192 tiles -- 15 % fewer operand bytes per flop through the LDS-DMA path
     // and 36 instead of 24 MFMAs per barrier (tools/split_lab: s2.pw1 264 vs 277 us, s3.pw1 200 vs 211)
+#ifndef ACX_SPLIT_NO_W192
     if (EPI == 1 && p.N % 192 == 0 && p.N >= 768 && !small) return launch_s_cfg<128, 192, 2, 2, EPI, GATHER>(p, s);
+#endif
     if (p.N % 128 == 0) {
         if (small) return launch_s_cfg<64, 128, 2, 2, EPI, GATHER>(p, s);
         return launch_s_cfg<128, 128, 2, 2, EPI, GATHER>(p, s);

@@ -10,14 +10,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float block_sum256(float v, float* red /*[4]*/) {
-    v = wave_sum(v);
-    __syncthreads();                       // protect red[] from the previous use
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
 // One workgroup of 768 threads per clip.  x NHWC (B,H3,7,768):
 //   mean over the 7 frequency columns (torch.mean(x, dim=3)), then max over time + mean over time,
 //   nn.LayerNorm(768, eps=1e-6) -> scene embedding; Linear 768->527 -> logits; sigmoid -> probs.

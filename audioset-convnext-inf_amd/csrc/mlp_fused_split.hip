@@ -51,7 +51,10 @@ struct FusedSCfg {
     static constexpr int kRowChunks = C / 4;                 // 16-B chunks per W1c row
     static constexpr int kSteps = C / 16;                    // k-steps of phase 1
     static constexpr int kUnits = 2 * (C / 32);              // (out tile, k-step) units of phase 2
-    static constexpr int kLead = 2;                          // iterations a weight image is requested ahead of use
+#ifndef ACX_FS_LEAD
+#define ACX_FS_LEAD 2
+#endif
+    static constexpr int kLead = ACX_FS_LEAD;                // iterations a weight image is requested ahead of use
     static constexpr int kRing = kLead + 1;
     static constexpr size_t kLdsBytes = 2 * kRing * (size_t)kHalfBytes + 4 * C * 4;
     __device__ static int swz1(int row) { return (C == 96) ? ((row >> 1) & 7) : (row & 15); }
@@ -323,9 +326,13 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
         ACX_FSTAMP(t2)
         ACX_FENCE
         // images requested this iteration may stay in flight; everything older must have landed
+#ifdef ACX_FS_DRAIN
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (L == 2 && j + 2 + L < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * Cfg::kPieces) : "memory");
         else if (L == 2 && j + L < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::kPieces) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #ifndef ACX_FSLAB_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif

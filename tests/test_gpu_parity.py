@@ -292,3 +292,28 @@ def test_split_batch_is_graph_capturable_and_exact(model):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, parts)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32_split"])
+def test_weight_scale_extremes(synth_sd, precision):
+    """Per-layer power-of-two weight scaling of the split arithmetic (acx_finalize): an all-zero pwconv2, a pwconv1
+    scaled down by 1e-6 and a pwconv2 scaled up by 64 must still track the oracle (the fp32 path takes the same
+    test so that the tolerances are comparable)."""
+    from oracle import ref_cpu
+    sd = {k: v.clone() for k, v in synth_sd.items()}
+    sd["stages.0.1.pwconv2.weight"].zero_()
+    sd["stages.1.0.pwconv1.weight"].mul_(1e-6)
+    sd["stages.2.3.pwconv2.weight"].mul_(64.0)
+    sd["stages.2.3.gamma"].mul_(1.0 / 64.0)
+    sd["downsample_layers.2.1.weight"].mul_(1e-3)
+    m = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
+                      use_speed_perturb=False)
+    m.load_state_dict(sd)
+    m = m.to("cuda").eval().set_precision(precision)
+    wav = synth.synth_waveforms(2, 40000, seed=21)
+    ref = ref_cpu.forward(sd, wav)
+    out = m(wav.cuda())
+    d = maxdiff(out["clipwise_logits"], ref["clipwise_logits"])
+    print("weight-scale extremes, %s: logits max abs diff %.3g" % (precision, d))
+    assert d < E2E_TOL
+    assert maxdiff(m.forward_frame_embeddings(wav.cuda()), ref_cpu.forward_frame_embeddings(sd, wav)) < E2E_TOL
