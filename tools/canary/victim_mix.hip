@@ -5,8 +5,11 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ in, unsi
     __shared__ float lds[4096];
     __shared__ float2 lds2[4096];
     __shared__ float4 lds4[2048];
+    struct cf4 { float x, y; };                 // 4-byte aligned pair -> ds_write2_b32 / ds_read2_b32
+    __shared__ cf4 ldsc[4096 + 512];
     const int tid = threadIdx.x;
     unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0, s8 = 0;
+    unsigned long long s9 = 0;
     for (int r = 0; r < rounds; ++r) {
         const size_t base = ((size_t)blockIdx.x * rounds + r) * 4096 % (size_t)n;
         // class 0: scalar-width vector loads
@@ -36,6 +39,14 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ in, unsi
         for (int k = 0; k < 8; ++k) { const float4 q = lds4[(tid + 256 * k) & 2047]; t4 += q.x + q.y - q.z + q.w; }
         __syncthreads();
         s5 += __float_as_uint(t2); s6 += __float_as_uint(t4);
+        // class 8: the FFT exchange shape: 4-byte-aligned pairs, padded index i + (i >> 3), 8 consecutive per lane out,
+        //          stride-64 in (compiles to ds_write2_b32 / ds_read2_b32)
+        for (int k = 0; k < 16; ++k) { const int i = ((tid * 16 + k) * 1) & 4095; cf4 q; q.x = a[k & 3] + k; q.y = a[(k + 2) & 3] - k; ldsc[i + (i >> 3)] = q; }
+        __syncthreads();
+        float tc = 0.f;
+        for (int k = 0; k < 16; ++k) { const int i = (tid + 256 * k) & 4095; const cf4 q = ldsc[i + (i >> 3)]; tc += q.x * 1.5f - q.y; }
+        __syncthreads();
+        s9 += __float_as_uint(tc);
         // class 3: transcendental + fma chain
         float u = a[0];
         for (int k = 0; k < 8; ++k) u = __sinf(u) * 1.7f + __log2f(fabsf(u) + 1.5f);
@@ -47,7 +58,7 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ in, unsi
     }
     atomicAdd(&sums[0], s0 * (tid + 1)); atomicAdd(&sums[1], s1 * (tid + 1)); atomicAdd(&sums[2], s2 * (tid + 1));
     atomicAdd(&sums[3], s3 * (tid + 1)); atomicAdd(&sums[4], s4 * (tid + 1));
-    atomicAdd(&sums[5], s5 * (tid + 1)); atomicAdd(&sums[6], s6 * (tid + 1)); atomicAdd(&sums[7], s7 * (tid + 1));
+    atomicAdd(&sums[5], s5 * (tid + 1)); atomicAdd(&sums[6], s6 * (tid + 1)); atomicAdd(&sums[7], s7 * (tid + 1)); atomicAdd(&sums[8], s9 * (tid + 1));
 }
 extern "C" int victim_launch(const float* in, unsigned long long* sums, int blocks, int rounds, int n, void* stream) {
     victim<<<blocks, 256, 0, (hipStream_t)stream>>>(in, sums, rounds, n);
