@@ -317,3 +317,18 @@ def test_weight_scale_extremes(synth_sd, precision):
     print("weight-scale extremes, %s: logits max abs diff %.3g" % (precision, d))
     assert d < E2E_TOL
     assert maxdiff(m.forward_frame_embeddings(wav.cuda()), ref_cpu.forward_frame_embeddings(sd, wav)) < E2E_TOL
+
+
+@pytest.mark.parametrize("L", [96123, 960000])
+def test_e2e_odd_and_long_clips(model, synth_sd, L):
+    """MANIFEST.json shape cases: an odd length (T = 301, stage heights 76/38/19/9) and a 30 s clip (T = 3001):
+    shapes as the reference produces them and values against the oracle."""
+    from oracle import ref_cpu
+    wav = synth.synth_waveforms(1, L, seed=400 + L % 7)
+    ref = ref_cpu.forward(synth_sd, wav)
+    out = model(wav.cuda())
+    fr = model.forward_frame_embeddings(wav.cuda())
+    h3, w3 = ref_cpu.out_hw(L)[3]
+    assert out["clipwise_logits"].shape == (1, 527) and fr.shape == (1, 768, h3, w3)
+    assert maxdiff(out["clipwise_logits"], ref["clipwise_logits"]) < E2E_TOL
+    assert maxdiff(fr, ref_cpu.forward_frame_embeddings(synth_sd, wav)) < E2E_TOL
