@@ -93,6 +93,7 @@ struct acx_ctx {
     int* d_mel_len = nullptr;     // [224]
     int* d_mel_off = nullptr;     // [224] offset into d_mel_w
     float* d_mel_w = nullptr;     // banded mel weights
+    int mel_w_len = 0;            // number of floats in d_mel_w
     float* d_bn_scale = nullptr;  // [224]
     float* d_bn_shift = nullptr;  // [224]
     // stem

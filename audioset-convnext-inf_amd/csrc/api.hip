@@ -203,6 +203,7 @@ static int finalize_impl(acx_ctx* c) {
         ACX_TRY(upload(c, len, &c->d_mel_len));
         ACX_TRY(upload(c, off, &c->d_mel_off));
         ACX_TRY(upload(c, band, &c->d_mel_w));
+        c->mel_w_len = (int)band.size();
     }
     {
         const auto &w = W(c, "bn0.weight"), &b = W(c, "bn0.bias"), &mu = W(c, "bn0.running_mean"),

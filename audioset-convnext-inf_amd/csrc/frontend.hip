@@ -22,7 +22,10 @@ __device__ __forceinline__ float wave_sum_dbg(float v) {
 }
 #endif
 
+constexpr int kMelLds = 1024;        // banded mel weights kept in LDS when they fit (librosa's 224-bin bank: 884)
+
 struct FrontLds {
+    float melw[kMelLds];
     cf tw[1024];
     cf buf[kFrontWaves][2][kFftBufSlots];
     float P[kFrontWaves][520];
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                                                      const int* __restrict__ mel_start,
                                                      const int* __restrict__ mel_len,
                                                      const int* __restrict__ mel_off,
-                                                     const float* __restrict__ mel_w,
+                                                     const float* __restrict__ mel_w, int mel_w_len,
                                                      const float* __restrict__ bn_scale,
                                                      const float* __restrict__ bn_shift, float* __restrict__ out) {
     __shared__ FrontLds lds;
@@ -42,6 +45,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
     const int lane = tid & 63;
     const int wave = tid >> 6;
     for (int i = tid; i < 1024; i += 256) lds.tw[i] = cf_make(twiddle[2 * i], twiddle[2 * i + 1]);
+    const bool mel_in_lds = mel_w_len <= kMelLds;      // else the filter loop reads the weights from global memory
+    if (mel_in_lds)
+        for (int i = tid; i < mel_w_len; i += 256) lds.melw[i] = mel_w[i];
 
     // this lane's mel bins (224 = 3.5 x 64) and their band descriptors
     int mstart[4], mlen[4], moff[4];
@@ -149,9 +155,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float acc = 0.f;
-            const float* w = mel_w + moff[i];
             const float* p = P + mstart[i];
-            for (int q = 0; q < mlen[i]; ++q) acc = fmaf(p[q], w[q], acc);
+            if (mel_in_lds) {
+                const float* w = lds.melw + moff[i];
+                for (int q = 0; q < mlen[i]; ++q) acc = fmaf(p[q], w[q], acc);
+            } else {
+                const float* w = mel_w + moff[i];
+                for (int q = 0; q < mlen[i]; ++q) acc = fmaf(p[q], w[q], acc);
+            }
             float db = 10.0f * log10f(fmaxf(acc, 1e-10f));
             int m = lane + 64 * i;
             if (valid && m < kMels) out[f * kMels + m] = fmaf(db, msc[i], msh[i]);
@@ -182,7 +193,7 @@ int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* 
     ProfScope ps(c, ACX_K_FRONTEND, s);
     logmel_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(wav, L, T, nframes, c->d_hann, c->d_twiddle,
                                                                 c->d_mel_start, c->d_mel_len, c->d_mel_off,
-                                                                c->d_mel_w, bn ? c->d_bn_scale : d_one,
+                                                                c->d_mel_w, c->mel_w_len, bn ? c->d_bn_scale : d_one,
                                                                 bn ? c->d_bn_shift : d_zero, out);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
