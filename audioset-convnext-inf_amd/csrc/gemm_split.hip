@@ -304,7 +304,7 @@ typedef __bf16 dbg_b8 __attribute__((ext_vector_type(8)));
     if (EPI == 1) {
         GeluConsts gk;          // GELU of v = a * sinv, result x kSplitHiddenScale (see split_math.h)
         gk.ps = 0.3275911f * 0.70710678f * sinv;
-        gk.cs = -0.72134752f * sinv * sinv;
+        gk.cq = 0.84932180f * sinv;       // sqrt(log2(e) / 2): exp(-v^2 / 2) = exp2(-(cq a)^2)
         gk.ca = -0.5f * sinv * kSplitHiddenScale;
         gk.cb = sinv * kSplitHiddenScale;
         const float binv = 1.0f / sinv;     // a power of two

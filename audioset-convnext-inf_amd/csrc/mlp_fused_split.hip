@@ -177,7 +177,7 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
     const int w2row = l31 * 128;
     GeluConsts gk;
     gk.ps = 0.3275911f * 0.70710678f * sinv1;
-    gk.cs = -0.72134752f * sinv1 * sinv1;
+    gk.cq = 0.84932180f * sinv1;       // sqrt(log2(e) / 2): exp(-v^2 / 2) = exp2(-(cq a)^2)
     gk.ca = -0.5f * sinv1 * kSplitHiddenScale;
     gk.cb = sinv1 * kSplitHiddenScale;
 

@@ -16,12 +16,13 @@ __device__ __forceinline__ f32x2 bc2(float v) { f32x2 r; r.x = v; r.y = v; retur
 
 // v = a * s;  g = gelu_erf(v) * kH (A&S 7.1.26, see gemm.hip) for two values, in three pieces; the result comes
 // back as packed fp16 hi / lo halves
-struct GeluConsts { float ps, cs, ca, cb; };
+struct GeluConsts { float ps, cq, ca, cb; };
 __device__ __forceinline__ void gelu_piece1(f32x2 a, const GeluConsts k, f32x2& av, f32x2& t, f32x2& e) {
     av.x = __builtin_fabsf(a.x); av.y = __builtin_fabsf(a.y);
     const f32x2 den = fma2(av, bc2(k.ps), bc2(1.0f));
     t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
-    const f32x2 ex = a * a * bc2(k.cs);
+    const f32x2 u = a * bc2(k.cq);                  // scaled first: a * a alone may overflow for very small weights
+    const f32x2 ex = -(u * u);
     e.x = __builtin_amdgcn_exp2f(ex.x); e.y = __builtin_amdgcn_exp2f(ex.y);
 }
 __device__ __forceinline__ void gelu_piece2(f32x2 a, f32x2 av, f32x2 t, f32x2 e, const GeluConsts k, f32x2& g) {

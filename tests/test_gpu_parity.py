@@ -306,6 +306,7 @@ def test_weight_scale_extremes(synth_sd, precision):
     sd["stages.2.3.pwconv2.weight"].mul_(64.0)
     sd["stages.2.3.gamma"].mul_(1.0 / 64.0)
     sd["downsample_layers.2.1.weight"].mul_(1e-3)
+    sd["stages.3.1.pwconv1.weight"].mul_(1e-14)          # accumulator scale 2^75: the GELU argument must not overflow
     m = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
                       use_speed_perturb=False)
     m.load_state_dict(sd)
