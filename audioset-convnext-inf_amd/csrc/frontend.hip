@@ -27,9 +27,8 @@ constexpr int kMelLds = 1024;        // banded mel weights kept in LDS when they
 struct FrontLds {
     float melw[kMelLds];
     cf tw[1024];
-    cf buf[kFrontWaves][2][kFftBufSlots];
-    float P[kFrontWaves][520];
-};
+    cf buf[kFrontWaves][2][kFftBufSlots];      // buf[w][1] doubles as the power spectrum P (513 floats) once pass 3 has
+};                                             // read it: 49 KB per workgroup = 3 workgroups per CU
 
 __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wav, long long L, int T,
                                                      long long nframes, const float* __restrict__ hann,
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         for (int r = 0; r < 8; ++r) bufA[fft_pad(dst + r * 64)] = v[r];
         __syncthreads();
         // power spectrum, 513 bins
-        float* P = lds.P[wave];
+        float* P = reinterpret_cast<float*>(bufB);       // bufB was last read before the barrier above
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             int k = lane + 64 * r;
