@@ -431,9 +431,14 @@ static int launch_dw_cfg(const BlockW& w, int C, const float* x, float* y, int B
     // Workgroups = columns x row segments.  Two workgroups are resident per CU (512 slots): aim at a whole
     // number of rounds (3 x 512) -- a fractional last round idles half the chip for a whole workgroup life
     // (measured 4.5 rounds = 5) -- with segments of at least 2 row tiles to amortise the ring prologue.
-    int n_seg = (int)((1536 + columns / 2) / columns);
+    // (stage 2, 768 columns: ONE segment of 4 tiles per workgroup beats two of 2 -- 61 vs 73 us in tools/dw_lab --
+    //  although 768 workgroups are only 1.5 rounds: the ring prologue is the larger cost)
+    int n_seg = columns >= 768 ? 1 : (int)((1536 + columns / 2) / columns);
     if (n_seg > tiles_h / 2) n_seg = tiles_h / 2;
     if (n_seg < 1) n_seg = 1;
+#ifdef ACX_LAB_DW_NSEG       // diagnostic (tools/dw_lab.hip): force the number of row segments
+    n_seg = ACX_LAB_DW_NSEG > tiles_h ? tiles_h : ACX_LAB_DW_NSEG;
+#endif
     const long long blocks = columns * n_seg;
     dwconv7_kernel<TW, TH><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(
         x, y, w.dw, w.dwb, H, W, C, tiles_w, tiles_h, n_seg);
