@@ -40,6 +40,13 @@ __device__ __forceinline__ void lds_dma16_s(const char* gsrc, char* lds_wave_bas
 #ifdef ACX_SLAB_NO_DMA      // diagnostic: no operand traffic at all (LDS holds garbage)
     return;
 #endif
+#ifdef ACX_DBG_PLAIN_LOADS  // diagnostic: the same bytes by ordinary 16-B loads into registers (LDS keeps garbage)
+    {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(gsrc + 16 * (threadIdx.x & 63) * 0);
+        asm volatile("" :: "v"(v));
+        return;
+    }
+#endif
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
@@ -132,6 +139,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
     }
     const int a_frag_off = wm * TM * 32 * kSRowBytes;
     const int b_frag_off = wn * TN * 32 * kSRowBytes;
+#ifdef ACX_DBG_NO_LDSREAD
+#define ACX_READ_FRAGS(F, abase, bbase, s) { _Pragma("unroll") for (int i = 0; i < TM; ++i) { asm volatile("" : "+v"(F##ah[i])); asm volatile("" : "+v"(F##al[i])); } _Pragma("unroll") for (int j = 0; j < TN; ++j) { asm volatile("" : "+v"(F##bh[j])); asm volatile("" : "+v"(F##bl[j])); } }
+#else
 #define ACX_READ_FRAGS(F, abase, bbase, s)                                                              \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
@@ -143,6 +153,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
             F##bl[j] = *reinterpret_cast<const f32x4*>((bbase) + j * 32 * kSRowBytes + foff_lo[s]);    \
         }                                                                                              \
     }
+#endif
 #define ACX_H8(x) __builtin_bit_cast(h8, x)
 #ifdef ACX_SLAB_NO_MFMA
 #define ACX_MFMA1(term, i, j, F) asm volatile("" :: "v"(F##ah[i]), "v"(F##bl[j]), "v"(F##al[i]), "v"(F##bh[j]));
