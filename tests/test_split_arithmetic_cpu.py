@@ -1,0 +1,59 @@
+"""The number format behind the default arithmetic (csrc/gemm_split.hip), checked on the CPU:
+an fp32 value carried as fp16 hi + fp16 lo keeps 24 significant bits, and hi*hi + hi*lo + lo*hi with fp32
+accumulation is as close to the exact product sum as an fp32 FMA chain is.  (The kernels themselves are tested on the
+GPU; this pins the error analysis the design rests on.)"""
+import numpy as np
+import pytest
+import torch
+
+
+def split16(x, scale):
+    """hi, lo as float32 tensors holding exactly representable fp16 values of x * scale."""
+    v = x * scale
+    hi = v.to(torch.float16).to(torch.float32)
+    lo = (v - hi).to(torch.float16).to(torch.float32)
+    return hi, lo
+
+
+def pow2_scale(x):
+    mx = float(x.abs().max())
+    return 2.0 ** (14 - int(np.floor(np.log2(mx))))
+
+
+@pytest.mark.parametrize("scale_in", [1.0, 1e-3, 27.0])
+def test_two_fp16_halves_keep_24_bits(scale_in):
+    torch.manual_seed(0)
+    x = torch.randn(1 << 16) * scale_in
+    s = pow2_scale(x)
+    hi, lo = split16(x, s)
+    rec = (hi.double() + lo.double()) / s
+    rel = ((rec - x.double()).abs() / x.double().abs().clamp_min(1e-30))
+    big = x.abs() > float(x.abs().max()) * 2.0 ** -13          # operands within 2^13 of the largest one
+    assert float(rel[big].max()) <= 2.0 ** -22                 # <= one fp32 ulp: the representation is not the limit
+    assert bool((hi.abs() <= 65504).all())
+
+
+@pytest.mark.parametrize("K,act_scale", [(96, 2048.0), (384, 2048.0), (1536, 16.0)])
+def test_three_term_product_matches_fp32_matmul_error(K, act_scale):
+    torch.manual_seed(1)
+    M, N = 256, 192
+    a = torch.randn(M, K) * (1.0 if act_scale == 2048.0 else 3.0)          # LayerNorm outputs / hidden activations
+    w = torch.randn(N, K) * 0.05
+    exact = a.double() @ w.double().T
+    ws = pow2_scale(w)
+    ah, al = split16(a, act_scale)
+    wh, wl = split16(w, ws)
+    # every partial product of two fp16 numbers is exact in fp32; the MFMA accumulates in fp32
+    acc = torch.zeros(M, N)
+    for x, y in ((al, wh), (ah, wl), (ah, wh)):
+        acc = acc + x @ y.T
+    got = acc.double() / (act_scale * ws)
+    plain = (a @ w.T).double()
+    err_split = float((got - exact).abs().max())
+    err_fp32 = float((plain - exact).abs().max())
+    scale = float(exact.abs().max())
+    print("K=%d: split %.3g, plain fp32 matmul %.3g (relative to max |c| = %.3g)" % (K, err_split / scale, err_fp32 / scale, scale))
+    assert err_split <= 2.0 * err_fp32 + 1e-7 * scale
+    # dropping the lo halves altogether (plain fp16 operands) is 2-3 orders of magnitude worse: the terms matter
+    err_hi_only = float(((ah @ wh.T).double() / (act_scale * ws) - exact).abs().max())
+    assert err_hi_only > 50 * err_split
