@@ -4,8 +4,9 @@
 // Without operand traffic its four consumer waves per CU nearly match the eight mixed waves of gemm_split (180 vs 161
 // us); with it they lose 90 us (vs 57): four loader waves issuing 8 LDS-DMA pieces each per step (60-180 cycles of
 // issue apiece) cannot feed a step of 768 MFMA cycles, and the per-step barrier ties the consumers to them.  More
-// loader waves do not fit the register budget (12 waves -> 170 VGPRs, the consumers need 203-246).  What would: fewer
-// operand bytes per flop (256-row tiles).  To try it again: add it to csrc/Makefile, declare the two entry points in
+// loader waves (-DACX_WS_LOADERS=8: 12 waves, 168 VGPRs, the epilogue spills) change nothing in the main loop either
+// (260 vs 271 us without epilogue): the loaders wait for data, not for issue slots.  What would help: fewer operand
+// bytes per flop (256-row tiles).  To try it again: add it to csrc/Makefile, declare the two entry points in
 // acx_internal.h and route run_mlp_split through launch_gemm_split_ws when gemm_split_ws_supported().
 // K4w -- split-fp16 GEMM (see gemm_split.hip for the arithmetic and the S16 operand format) as a PERSISTENT,
 // WAVE-SPECIALISED kernel for the large pointwise contractions of stages 2-3:
@@ -66,8 +67,13 @@ __device__ __forceinline__ long long ws_tile_of(long long i, long long bid, long
 }
 
 // EPI: 1 bias + GELU -> S16 (scaled by kSplitHiddenScale), 2 bias + residual -> fp32
+#ifndef ACX_WS_LOADERS
+#define ACX_WS_LOADERS 4
+#endif
+constexpr int kWsLoaders = ACX_WS_LOADERS;          // loader waves (4 or 8); each stages 128 / kWsLoaders rows of A and of B
+constexpr int kWsLP = 16 / kWsLoaders;              // 1-KB pieces per operand per loader per step
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_split_ws_kernel(GemmWsParams p) {
+__global__ __launch_bounds__(256 + 64 * kWsLoaders) void gemm_split_ws_kernel(GemmWsParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [kWsStages][A tile | B tile]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,18 +89,18 @@ __global__ __launch_bounds__(512) void gemm_split_ws_kernel(GemmWsParams p) {
         // =========================================== loaders ===========================================================
         const int lw = wave - 4;
         const int prow = lane >> 3, pchunk = lane & 7;
-        // per step this wave stages rows [32 lw, 32 lw + 32) of A and of B: 4 + 4 pieces of 8 rows
-        const char* a_src[4];
-        const char* b_src[4];
-        char* const dst0 = smem + (32 * lw) * kWsRowBytes;
+        // per step this wave stages rows [8 kWsLP lw, +8 kWsLP) of A and of B: kWsLP + kWsLP pieces of 8 rows
+        const char* a_src[kWsLP];
+        const char* b_src[kWsLP];
+        char* const dst0 = smem + (8 * kWsLP * lw) * kWsRowBytes;
         long long cur_i = -1;
         auto set_tile = [&](long long i) {
             const long long t = ws_tile_of(i, bid, nwg, p.tiles);
             const long long tile_m = t / p.tiles_n;
             const int tile_n = (int)(t - tile_m * p.tiles_n);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = 32 * lw + 8 * q + prow;
+            for (int q = 0; q < kWsLP; ++q) {
+                const int row = 8 * kWsLP * lw + 8 * q + prow;
                 const int chunk = pchunk ^ ((row >> 1) & 7);
                 long long m = tile_m * 128 + row;
                 if (m >= p.M) m = p.M - 1;
@@ -110,14 +116,14 @@ __global__ __launch_bounds__(512) void gemm_split_ws_kernel(GemmWsParams p) {
             char* d = dst0 + (int)(g % kWsStages) * (2 * kWsTile);
             const long long ko = (long long)kt * kWsBK * 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) lds_dma16_w(a_src[q] + ko, d + q * 8 * kWsRowBytes);
+            for (int q = 0; q < kWsLP; ++q) lds_dma16_w(a_src[q] + ko, d + q * 8 * kWsRowBytes);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) lds_dma16_w(b_src[q] + ko, d + kWsTile + q * 8 * kWsRowBytes);
+            for (int q = 0; q < kWsLP; ++q) lds_dma16_w(b_src[q] + ko, d + kWsTile + q * 8 * kWsRowBytes);
         };
         for (long long g = 0; g < kWsStages - 1 && g < total_steps; ++g) issue(g);
         for (long long g = 0; g <= total_steps; ++g) {
             // step g landed?  (8 pieces per step and wave; the kWsStages-2 younger steps may stay in flight)
-            if (g + kWsStages - 2 < total_steps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kWsStages - 2) * 8) : "memory");
+            if (g + kWsStages - 2 < total_steps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kWsStages - 2) * 2 * kWsLP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (g + kWsStages - 1 < total_steps) issue(g + kWsStages - 1);
@@ -330,7 +336,7 @@ static int launch_ws_epi(const GemmWsParams& p, hipStream_t s) {
         attr_set = true;
     }
     const long long blocks = p.tiles < num_cu ? p.tiles : num_cu;
-    gemm_split_ws_kernel<EPI><<<dim3((unsigned)blocks), dim3(512), kWsLdsBytes, s>>>(p);
+    gemm_split_ws_kernel<EPI><<<dim3((unsigned)blocks), dim3(256 + 64 * kWsLoaders), kWsLdsBytes, s>>>(p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

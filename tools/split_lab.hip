@@ -5,6 +5,9 @@
 #include <cstring>
 #include <vector>
 #include "../audioset-convnext-inf_amd/csrc/gemm_split.hip"
+#ifdef ACX_LAB_WS
+#include "experimental/gemm_split_ws.hip"
+#endif
 
 namespace acx {
 void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
@@ -46,16 +49,23 @@ int main(int argc, char** argv) {
         acx::GemmSplitArgs g{};
         g.A = A; g.Wt = W; g.bias = bias; g.out = O; g.resid = s.epi == acx::EPI_RESID ? (const float*)O : nullptr;
         g.M = s.M; g.N = s.N; g.K = s.K; g.sinv = 1e-3f; g.epi = s.epi; g.cls = 0;
-        if (acx::launch_gemm_split(nullptr, g, 0) != 0) return 1;
+#ifdef ACX_LAB_WS
+        const bool ws = acx::gemm_split_ws_supported(g);
+        auto launch = [&]() { return ws ? acx::launch_gemm_split_ws(nullptr, g, 0) : acx::launch_gemm_split(nullptr, g, 0); };
+#else
+        const bool ws = false;
+        auto launch = [&]() { return acx::launch_gemm_split(nullptr, g, 0); };
+#endif
+        if (launch() != 0) return 1;
         hipDeviceSynchronize();
         hipEventRecord(e0, 0);
-        for (int r = 0; r < reps; ++r) acx::launch_gemm_split(nullptr, g, 0);
+        for (int r = 0; r < reps; ++r) launch();
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
         double tf = 2.0 * s.M * s.N * s.K / (ms * 1e-3) / 1e12;
         const int blocks = s.name[1] == '0' || s.name[1] == '1' || s.name[1] == '3' ? 3 : 9;
         total += ms * blocks;
-        printf("%-8s M=%-8lld N=%-5d K=%-5d  %8.1f us  %6.1f TF fp32-equivalent (%4.1f%% of 833 = fp16 peak / 3)\n", s.name, s.M, s.N, s.K,
+        printf("%-8s%s M=%-8lld N=%-5d K=%-5d  %8.1f us  %6.1f TF fp32-equivalent (%4.1f%% of 833 = fp16 peak / 3)\n", s.name, ws ? " [ws]" : "", s.M, s.N, s.K,
                ms * 1e3, tf, 100 * tf / 833.3);
     }
     printf("all 18 blocks: %.2f ms\n", total);
