@@ -28,6 +28,10 @@ namespace acx {
 constexpr int kSRowBytes = 128;     // 32 k per LDS row
 constexpr int kSBK = 32;
 
+#ifdef ACX_SLAB_CLOCK       // diagnostic build (tools/split_lab.hip): in-kernel shader clock = d s_memtime / d s_memrealtime
+__device__ unsigned long long acx_gs_clock[4];
+#endif
+
 struct GemmSParams {
     const char* A; const char* Wt; const float* bias; void* out; const float* resid;
     long long M; int N; int K;
@@ -72,6 +76,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+#ifdef ACX_SLAB_CLOCK
+    unsigned long long ck0 = 0, rt0 = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck0), "=s"(rt0) :: "memory");
+#endif
     long long lid = blockIdx.x;
     {   // XCD-contiguous tile order (see gemm.hip)
         const long long nwg = gridDim.x, per = (nwg + 7) >> 3, full = nwg - (per - 1) * 8;
@@ -302,6 +310,13 @@ typedef __bf16 dbg_b8 __attribute__((ext_vector_type(8)));
 #undef ACX_TOUCH
 #undef ACX_H8
 
+#ifdef ACX_SLAB_CLOCK
+    {
+        unsigned long long ck1 = 0, rt1 = 0;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck1), "=s"(rt1) :: "memory");
+        if (tid == 0) { atomicAdd(&acx_gs_clock[0], ck1 - ck0); atomicAdd(&acx_gs_clock[1], rt1 - rt0); atomicAdd(&acx_gs_clock[2], 1ULL); }
+    }
+#endif
 #ifdef ACX_SLAB_NO_EPI      // diagnostic (tools/split_lab.hip): main loop only
     {
         float t = 0.f;

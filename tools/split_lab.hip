@@ -69,5 +69,13 @@ int main(int argc, char** argv) {
                ms * 1e3, tf, 100 * tf / 833.3);
     }
     printf("all 18 blocks: %.2f ms\n", total);
+#ifdef ACX_SLAB_CLOCK
+    {
+        unsigned long long ck[4];
+        hipMemcpyFromSymbol(ck, HIP_SYMBOL(acx::acx_gs_clock), sizeof(ck));
+        printf("in-kernel clock over the k-loops of all launches: %.3f GHz (%.0f cycles, %.2f us per workgroup)\n",
+               (double)ck[0] / ((double)ck[1] * 10.0), (double)ck[0] / ck[2], (double)ck[1] / ck[2] / 100.0);
+    }
+#endif
     return 0;
 }
