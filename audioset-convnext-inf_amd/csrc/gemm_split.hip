@@ -179,6 +179,18 @@ typedef __bf16 dbg_b8 __attribute__((ext_vector_type(8)));
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8((term) == 0 ? F##bl[j] : F##bh[j]),     \
                                                        ACX_H8((term) == 1 ? F##al[i] : F##ah[i]), acc[i][j], 0, 0, 0); \
     __builtin_amdgcn_s_nop(7);
+#elif defined(ACX_DBG_SHAPE16)      /* diagnostic: the same loop with 16x16x32 MFMAs, two per 32x32x16 (same flops, same
+                                       operands and LDS reads; numerically meaningless) -- what would the other shape buy? */
+typedef float dbg_f4 __attribute__((ext_vector_type(4)));
+#define ACX_MFMA1(term, i, j, F)                                                                       \
+    {                                                                                                  \
+        dbg_f4 lo_ = __builtin_shufflevector(acc[i][j], acc[i][j], 0, 1, 2, 3);                        \
+        dbg_f4 hi_ = __builtin_shufflevector(acc[i][j], acc[i][j], 4, 5, 6, 7);                        \
+        lo_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ACX_H8((term) == 0 ? F##bl[j] : F##bh[j]), ACX_H8((term) == 1 ? F##al[i] : F##ah[i]), lo_, 0, 0, 0); \
+        hi_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ACX_H8((term) == 1 ? F##al[i] : F##ah[i]), ACX_H8((term) == 0 ? F##bl[j] : F##bh[j]), hi_, 0, 0, 0); \
+        acc[i][j][0] = lo_[0]; acc[i][j][1] = lo_[1]; acc[i][j][2] = lo_[2]; acc[i][j][3] = lo_[3];    \
+        acc[i][j][4] = hi_[0]; acc[i][j][5] = hi_[1]; acc[i][j][6] = hi_[2]; acc[i][j][7] = hi_[3];    \
+    }
 #elif defined(ACX_DBG_ONE_TERM)
 #define ACX_MFMA1(term, i, j, F)                                                                       \
     if ((term) == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bh[j]), ACX_H8(F##ah[i]), acc[i][j], 0, 0, 0); \

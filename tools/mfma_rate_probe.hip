@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
                 if (SHAPE == 32) c32[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 3], b[(u + n) & 3], c32[n], 0, 0, 0);
                 else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)     // 4 x (16x16x32) = the flops of one 32x32x16
-                        c16[4 * n + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(u + q) & 3], b[(u + n) & 3], c16[4 * n + q], 0, 0, 0);
+                    for (int q = 0; q < 4; ++q)     // 4 x (16x16x32) = the flops of TWO 32x32x16
+                        c16[4 * n + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q], b[n & 3], c16[4 * n + q], 0, 0, 0);
                 }
             }
     }
@@ -53,7 +53,7 @@ void run(int wgs_per_cu, float* d, unsigned long long* dc) {
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long c[2]; hipMemcpy(c, dc, 16, hipMemcpyDeviceToHost);
-    const double nm = (double)iters * 8 * NACC;      // in units of one 32x32x16 worth of flops
+    const double nm = (double)iters * 8 * NACC * (SHAPE == 32 ? 1 : 2);      // in units of one 32x32x16 worth of flops
     const double tf = 2.0 * 32 * 32 * 16 * nm * 4 * 256 * wgs_per_cu / (ms * 1e-3) / 1e12;
     printf("%dx%d acc=%d waves/SIMD=%d %-7s: %5.1f cycles per 32x32x16-equivalent per wave, %4.0f TFLOP/s, in-kernel clock %.2f GHz\n",
            SHAPE, SHAPE, NACC, wgs_per_cu, RANDOM ? "random" : "ones", c[0] / nm, tf, c[0] / (c[1] * 10.0));
