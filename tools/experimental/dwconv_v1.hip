@@ -3,20 +3,18 @@
 // (convnext.py:61,78; F.layer_norm :532-535) needs.
 //
 // HBM-bound: algorithmic bytes = read x + write y = 2*C*H*W*4 B per clip per block
-// (10.84 / 5.42 / 2.71 / 1.33 MB in stages 0-3).  12.25 FLOP/B: the fp32 FMAs (0.945 GFLOP per clip) take about
-// as long as the bytes, so everything else has to stay out of their way.  Lanes run along C (16 lanes x float2 =
-// one 128-B line per pixel), each thread keeps 2 adjacent output rows x WT=7 adjacent pixels x 2 channels in
-// registers; an input row (13 LDS reads) feeds both output rows, a kernel row's 7 weights are read once for the
-// pair.  The input rows and the 49x32 weight slice are staged through LDS; the batch is streamed as ONE tall
-// image (see the kernel), every input element is fetched from HBM once per column strip.
-#include "acx_internal.h"
+// (10.84 / 5.42 / 2.71 / 1.33 MB in stages 0-3).  12.25 FLOP/B, so the VALU must stay under
+// ~50 % busy to reach the HBM roofline: lanes run along C (float4 = 16 B per lane, 8 lanes = one
+// 128-B line per pixel), each thread keeps WT=7 adjacent output pixels x 4 channels in registers
+// and slides the 7-tap row over 13 LDS reads (49 FMA x 4 channels per 13+7 ds_read_b128).
+// The input halo tile and the 49x32 weight slice are staged through LDS once per workgroup.
+#include "../../audioset-convnext-inf_amd/csrc/acx_internal.h"
 
 namespace acx {
 
 constexpr int kDwSlice = 32;      // channels per workgroup (8 lanes x float4)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifdef ACX_LAB_DW_STAMP      // diagnostic build (tools/dw_lab.hip): where does a tile spend its cycles?
 __device__ unsigned long long acx_dw_stamps[8];
@@ -47,9 +45,8 @@ struct DwCfg {
 template <int TW, int TH>
 __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          const float* __restrict__ wt /*[49][C]*/,
-                                                         const float* __restrict__ bias, int B, int H, int W,
-                                                         int C, int tiles_w, int tiles_h, int n_seg,
-                                                         unsigned magic /* floor(2^32 / (H + 3)) + 1 */) {
+                                                         const float* __restrict__ bias, int H, int W, int C,
+                                                         int tiles_w, int tiles_h, int n_seg) {
     using Cfg = DwCfg<TW, TH>;
     static_assert(Cfg::kThreads == 256, "thread mapping assumes 256 threads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,7 +57,8 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
     int bid = blockIdx.x;
     const int slice = bid % (C / kDwSlice); bid /= (C / kDwSlice);
     const int tw = bid % tiles_w; bid /= tiles_w;
-    const int seg = bid;
+    const int seg = bid % n_seg; bid /= n_seg;
+    const long long b = bid;
     const int c0 = slice * kDwSlice;
     const int w0 = tw * TW;
     const int tid = threadIdx.x;
@@ -68,31 +66,11 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
     const int t_end = (int)((long long)tiles_h * (seg + 1) / n_seg);
     if (t_begin >= t_end) return;
 
-    // Prologue: ONE exposed memory latency.  The weight slice and both rounds of the first TH + 6 ring rows are
-    // requested back to back, the ring is zeroed underneath them, and only then does anything wait (three
-    // dependent round trips -- weights, rows, rows -- cost ~10 us per workgroup; stages 2-3 are little else).
-    f32x4 wreg[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        int i = tid + k * Cfg::kThreads;
-        if (i >= 49 * 8) i = 49 * 8 - 1;
-        wreg[k] = *reinterpret_cast<const f32x4*>(wt + (i >> 3) * C + c0 + 4 * (i & 7));
-    }
-    const float* xb = x + c0;
-    // The B images of the batch form ONE tall virtual image: H rows of clip 0, 3 rows of zeros, H rows of clip 1,
-    // ... (3 zero rows are all the 7x7 window ever sees between two clips, and consecutive clips are
-    // consecutive in memory), so the ring streams straight through the batch and a workgroup lives for many
-    // tiles whatever the image height -- per-image workgroups spent most of their life in ring prologue and
-    // store drain once H fell to 63 and 31 rows.  Virtual row v = n * (H + 3) + r is image n, row r (r >= H: gap).
-    const int Hp = H + 3;
-#define ACX_DW_VROW(v_, n_, r_, ok_)   /* v_ may be negative (rows above the first clip) */                  \
-    int n_, r_; bool ok_;                                                                                 \
-    {                                                                                                     \
-        const int vc_ = (v_) < 0 ? 0 : (v_);                                                              \
-        n_ = (int)__umulhi((unsigned)vc_, magic);                                                         \
-        r_ = vc_ - n_ * Hp;                                                                               \
-        ok_ = (v_) >= 0 && r_ < H && n_ < B;                                                              \
-    }
+    for (int i = tid; i < 49 * 8; i += Cfg::kThreads)
+        wl[i] = *reinterpret_cast<const f32x4*>(wt + (i >> 3) * C + c0 + 4 * (i & 7));
+    // columns outside the image are never written again: zero the whole ring once
+    for (int i = tid; i < Cfg::kRing * Cfg::kRowF4; i += Cfg::kThreads) ring[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + b * (long long)H * W * C + c0;
     const long long row_elems = (long long)W * C;
 
     // Per-thread staging plan for a step of TH image rows (float4 #k of this thread):
@@ -118,95 +96,70 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
     }
     const int g_origin = t_begin * TH - 3;             // image row kept in ring row 0 of this segment
     f32x4 rg[Cfg::kStage];
-#define ACX_DW_LOAD_FAST(real_row)   /* TH rows of one clip, starting at row real_row of the (B*H)-row tensor */ \
+#define ACX_DW_LOAD_FAST(first_row)   /* rows first_row .. +TH-1, all inside the image */                    \
     {                                                                                                     \
-        const long long roff = (long long)(real_row) * row_elems;                                         \
+        const long long roff = (long long)(first_row) * row_elems;                                        \
         _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k)                                           \
             rg[k] = *reinterpret_cast<const f32x4*>(st_ptr[k] + roff);                                    \
     }
-#define ACX_DW_LOAD_EDGE_TO(rg_, first_row)   /* some rows outside [0,H): clamp the row, zero at store time */ \
+#define ACX_DW_LOAD_EDGE(first_row)   /* some rows outside [0,H): clamp the row, zero at store time */      \
     _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {                                             \
-        ACX_DW_VROW((first_row) + st_row[k], n_, r_, ok_)                                                 \
-        const int gh = (n_ < B ? n_ : B - 1) * H + (r_ < H ? r_ : H - 1);     /* clamped: always a valid row */ \
-        (void)ok_;                                                                                        \
-        rg_[k] = *reinterpret_cast<const f32x4*>(st_ptr[k] + (long long)(gh - st_row[k]) * row_elems);    \
+        int gh = (first_row) + st_row[k];                                                                 \
+        gh = gh < 0 ? 0 : (gh >= H ? H - 1 : gh);                                                         \
+        rg[k] = *reinterpret_cast<const f32x4*>(st_ptr[k] + (long long)(gh - st_row[k]) * row_elems);     \
     }
-#define ACX_DW_LOAD_EDGE(first_row) ACX_DW_LOAD_EDGE_TO(rg, first_row)
-#define ACX_DW_STORE_FROM(rg_, first_row, max_rows, edge) /* registers -> ring rows of image rows first_row .. */ \
+#define ACX_DW_STORE(first_row, max_rows, edge) /* registers -> ring rows of image rows first_row .. */     \
     {                                                                                                     \
         const int slot0 = ((first_row) - g_origin) % Cfg::kRing;           /* wave-uniform */             \
         _Pragma("unroll") for (int k = 0; k < Cfg::kStage; ++k) {                                         \
             int slot = slot0 + st_row[k];                                                                 \
             if (slot >= Cfg::kRing) slot -= Cfg::kRing;                                                   \
-            f32x4 v = rg_[k];                                                                             \
+            f32x4 v = rg[k];                                                                              \
             bool keep = st_lds[k] >= 0 && st_row[k] < (max_rows);                                         \
             if (edge) {                                                                                   \
-                ACX_DW_VROW((first_row) + st_row[k], n_, r_, ok_)                                         \
-                if (!ok_) v = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+                const int gh = (first_row) + st_row[k];                                                   \
+                if (gh < 0 || gh >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};                                     \
             }                                                                                             \
             f32x4* dst = keep ? ring + slot * Cfg::kRowF4 + st_lds[k] : dummy + tid;                      \
             *dst = v;                                                                                     \
         }                                                                                                 \
     }
-#define ACX_DW_STORE(first_row, max_rows, edge) ACX_DW_STORE_FROM(rg, first_row, max_rows, edge)
-    // image rows [g_origin, g_origin + TH + 6) in two rounds (of the second only 6 rows are kept)
-    {
-        f32x4 rg2[Cfg::kStage];
-        ACX_DW_LOAD_EDGE(g_origin)
-        ACX_DW_LOAD_EDGE_TO(rg2, g_origin + TH)
-        __builtin_amdgcn_sched_barrier(0);
-        // columns outside the image are never written again: zero the whole ring once
-        for (int i = tid; i < Cfg::kRing * Cfg::kRowF4; i += Cfg::kThreads) ring[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();                               // ring zeroed before it is filled
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-            if (tid + k * Cfg::kThreads < 49 * 8) wl[tid + k * Cfg::kThreads] = wreg[k];
-        ACX_DW_STORE(g_origin, TH, true)
-        ACX_DW_STORE_FROM(rg2, g_origin + TH, 6, true)
-        __syncthreads();
-    }
+    __syncthreads();                                   // ring zeroed before the prologue fills it
+    // prologue: image rows [g_origin, g_origin + TH + 6) in two rounds (of the second only 6 rows are kept)
+    ACX_DW_LOAD_EDGE(g_origin)
+    ACX_DW_STORE(g_origin, TH, true)
+    ACX_DW_LOAD_EDGE(g_origin + TH)
+    ACX_DW_STORE(g_origin + TH, 6, true)
+    __syncthreads();
 
-    // Compute mapping: 16 lanes x float2 cover a pixel's 32 channels; a thread owns TWO adjacent output rows x
-    // WT = 7 adjacent pixels.  An input row read from LDS (13 float2) then feeds both output rows (kernel rows
-    // ky and ky-1), and a kernel row's 7 weights are read once for the pair: 8*13 + 49 = 153 8-byte reads per
-    // 28 outputs instead of 2 x (7*13 + 49) 16-byte reads per 2 x 28 with one row per thread -- the LDS pipe
-    // (128 B/clk per CU), not the VALU, was what bounded the FMA phase (4.5 k LDS cycles against 2.7 k of
-    // v_pk_fma_f32 per workgroup step).
-    const int l16 = tid & 15;
-    const int strip = (tid >> 4) % Cfg::kStrips;
-    const int rp = (tid >> 4) / Cfg::kStrips;          // row pair: output rows h0 + 2rp, h0 + 2rp + 1
-    const f32x2* const ring2 = reinterpret_cast<const f32x2*>(ring);
-    const f32x2* const wl2 = reinterpret_cast<const f32x2*>(wl);       // [49][16]
-    constexpr int kRowF2 = Cfg::kRowF4 * 2;
-    const f32x2 bv = *reinterpret_cast<const f32x2*>(bias + c0 + 2 * l16);
-    const int rd_off = (strip * Cfg::WT) * 16 + l16;   // float2 offset of this thread's first input column
-    float* const yb = y + (long long)(w0 + strip * Cfg::WT) * C + c0 + 2 * l16;
+    const int q = tid & 7;
+    const int strip = (tid >> 3) % Cfg::kStrips;
+    const int r = (tid >> 3) / Cfg::kStrips;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0 + 4 * q);
+    const int rd_off = (strip * Cfg::WT) * 8 + q;      // float4 offset of this thread's first input column
+    float* const yb = y + ((b * H) * (long long)W + w0 + strip * Cfg::WT) * C + c0 + 4 * q;
 
 #ifdef ACX_LAB_DW_STAMP
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, acc_s[5] = {0, 0, 0, 0, 0};
 #endif
-    f32x2 so0[Cfg::WT], so1[Cfg::WT];
+    f32x4 so[Cfg::WT];
 #pragma unroll
-    for (int i = 0; i < Cfg::WT; ++i) so0[i] = so1[i] = bv;
-    float *yp0 = nullptr, *yp1 = nullptr;              // where so0[] / so1[] belong (null: nothing pending)
+    for (int i = 0; i < Cfg::WT; ++i) so[i] = bv;
+    float* yp_prev = nullptr;                          // where so[] belongs (null: nothing pending)
 #ifdef ACX_LAB_DW_NOSTORE
-#define ACX_DW_FLUSH1(yp_, so_) if (yp_ != nullptr && so_[0][0] == 12345.678f) { _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x2*>(yp_ + (long long)i * C) = so_[i]; }
+#define ACX_DW_FLUSH if (yp_prev != nullptr && so[0][0] == 12345.678f) { _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x4*>(yp_prev + (long long)i * C) = so[i]; }
 #else
-#define ACX_DW_FLUSH1(yp_, so_) if (yp_ != nullptr) { _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x2*>(yp_ + (long long)i * C) = so_[i]; }
+#define ACX_DW_FLUSH if (yp_prev != nullptr) { _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x4*>(yp_prev + (long long)i * C) = so[i]; }
 #endif
-#define ACX_DW_FLUSH ACX_DW_FLUSH1(yp0, so0) ACX_DW_FLUSH1(yp1, so1)
     for (int t = t_begin; t < t_end; ++t) {
         const int h0 = t * TH;
         const bool more = t + 1 < t_end;
         ACX_STAMP(ts0)
         const int next_first = h0 + TH + 3;            // image rows of the next step (ring rows of the TH oldest)
-        // fast path: the TH rows of the next step belong to one clip (next_first >= 0 always)
-        const int nf_n = (int)__umulhi((unsigned)next_first, magic);
-        const int nf_r = next_first - nf_n * Hp;
-        const bool edge = nf_r + TH > H || nf_n >= B;
+        const bool edge = next_first + TH > H;         // (next_first >= 0 always)
 #ifndef ACX_LAB_DW_NOLOAD
         if (more) {
-            if (edge) { ACX_DW_LOAD_EDGE(next_first) } else { ACX_DW_LOAD_FAST(nf_n * H + nf_r) }
+            if (edge) { ACX_DW_LOAD_EDGE(next_first) } else { ACX_DW_LOAD_FAST(next_first) }
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
@@ -217,94 +170,96 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
         ACX_DW_FLUSH
         __builtin_amdgcn_sched_barrier(0);
 
-        f32x2 a0[Cfg::WT], a1[Cfg::WT];
+        f32x4 acc[Cfg::WT];
 #pragma unroll
-        for (int i = 0; i < Cfg::WT; ++i) a0[i] = a1[i] = bv;
-        int lw = l16;                     // opaque per tile: keeps hipcc from hoisting all 49 weight float2
-        asm volatile("" : "+v"(lw));      // (98 VGPRs) out of the tile loop -- they are re-read from LDS instead
-        const int base = (h0 - 3 - g_origin + 2 * rp) % Cfg::kRing;    // ring slot of input row h0 - 3 + 2rp
-        // The 8 input rows are software-pipelined by hand in HALF rows: the LDS reads of the next unit
-        // (7 or 6 input float2, and once per row the 7 weights of the next kernel row) are issued into
-        // a second register set BEFORE the packed FMAs of the current unit.  Input row i meets kernel row i for
-        // the upper output row and kernel row i-1 for the lower one: three weight sets rotate.
-        f32x2 iA[7], iB[6], wA[7], wB[7], wC[7];
-#define ACX_DW_ROWP(i_, p_)                                                                               \
-        const f32x2* p_;                                                                                  \
+        for (int i = 0; i < Cfg::WT; ++i) acc[i] = bv;
+        int qw = q;                       // opaque per tile: keeps hipcc from hoisting all 49 weight float4
+        asm volatile("" : "+v"(qw));      // (196 VGPRs) out of the tile loop -- they are re-read from LDS instead
+        const int base = (h0 - 3 - g_origin + r) % Cfg::kRing;    // ring slot of input row h0 - 3 + r
+        // The 7 kernel rows are software-pipelined by hand in HALF rows: the LDS reads of the next unit
+        // (7 or 6 input float4, and once per row the 7 weight float4 of the next kernel row) are issued into
+        // a second register set BEFORE the 49 packed FMAs of the current unit.  A wave issues at most one
+        // instruction per ~5 cycles and only two waves fit per SIMD, so every non-FMA instruction costs FMA
+        // time: one wait per unit (single asm touch), no per-element address math.
+        f32x4 iA[7], iB[6], wA[7], wB[7];
+#define ACX_DW_ROWP(ky_, p_)                                                                              \
+        const f32x4* p_;                                                                                  \
         {                                                                                                 \
-            int slot = base + (i_);                                                                       \
+            int slot = base + (ky_);                                                                      \
             if (slot >= Cfg::kRing) slot -= Cfg::kRing;                                                   \
-            p_ = ring2 + slot * kRowF2 + rd_off;                                                          \
+            p_ = ring + slot * Cfg::kRowF4 + rd_off;                                                      \
         }
-#define ACX_DW_READ_W(w_, ky_) _Pragma("unroll") for (int kx = 0; kx < 7; ++kx) w_[kx] = wl2[((ky_) * 7 + kx) * 16 + lw];
-#define ACX_DW_READ_I0(i_) { ACX_DW_ROWP(i_, p0_) _Pragma("unroll") for (int j = 0; j < 7; ++j) iA[j] = p0_[j * 16]; }
-#define ACX_DW_READ_I1(i_) { ACX_DW_ROWP(i_, p1_) _Pragma("unroll") for (int j = 0; j < 6; ++j) iB[j] = p1_[(7 + j) * 16]; }
-        // The packed FMAs are inline asm in a FIXED order.  Left to hipcc they are regrouped into per-accumulator
-        // chains (v_pk_fma_f32 a, x0, w0, a; s_nop; v_pk_fma_f32 a, x1, w1, a; ...: 254 hazard nops per tile and a
-        // dependent instruction every slot -- a wave could then fill at most half of its SIMD's issue slots and
-        // the FMA phase ran at 0.54 of the measured v_pk_fma_f32 rate); here the same accumulator returns after
-        // >= 2 (single output row) or >= 4 (both rows) other FMAs.  The LDS reads of the NEXT unit are issued in
-        // adjacent-column pairs (one ds_read2_b64 each) at even distances inside the FMA stream, fenced by
-        // sched_barrier so that they stay where they are put.
-#define ACX_DW_PKFMA(acc_, x_, w_) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc_) : "v"(x_), "v"(w_));
-#define ACX_DW_UNIT(i_, wc_, wp_, in_, jlo_, jhi_, nslots_, slot_fn_)                                      \
+#define ACX_DW_READ_W(w_, ky_) _Pragma("unroll") for (int kx = 0; kx < 7; ++kx) w_[kx] = wl[((ky_) * 7 + kx) * 8 + qw];
+#define ACX_DW_READ_I0(ky_) { ACX_DW_ROWP(ky_, p0_) _Pragma("unroll") for (int j = 0; j < 7; ++j) iA[j] = p0_[j * 8]; }
+#define ACX_DW_READ_I1(ky_) { ACX_DW_ROWP(ky_, p1_) _Pragma("unroll") for (int j = 0; j < 6; ++j) iB[j] = p1_[(7 + j) * 8]; }
+#ifdef ACX_LAB_DW_SCALAR_FMA
+#define ACX_DW_MAC(a_, i_, w_)                                                                             \
         {                                                                                                 \
-            constexpr int both_ = ((i_) >= 1 && (i_) <= 6) ? 2 : 1;                                       \
-            constexpr int total_ = ((jlo_) == 0 ? 28 : 21) * both_;                                       \
-            constexpr int gap_ = total_ / ((nslots_) + 1) > 0 ? total_ / ((nslots_) + 1) : 1;             \
-            int n_ = 0, sl_ = 0;                                                                          \
-            _Pragma("unroll") for (int j = (jlo_); j < (jhi_); ++j)                                       \
-            _Pragma("unroll") for (int kx = (j > 6 ? j - 6 : 0); kx <= (j > 6 ? 6 : j); ++kx) {           \
-                if ((i_) <= 6) { ACX_DW_PKFMA(a0[j - kx], in_[j - (jlo_)], wc_[kx]) ++n_; }               \
-                if ((i_) >= 1) { ACX_DW_PKFMA(a1[j - kx], in_[j - (jlo_)], wp_[kx]) ++n_; }               \
-                if (sl_ < (nslots_) && n_ >= (sl_ + 1) * gap_) {                                          \
-                    __builtin_amdgcn_sched_barrier(0);                                                    \
-                    slot_fn_(sl_);                                                                        \
-                    ++sl_;                                                                                \
-                    __builtin_amdgcn_sched_barrier(0);                                                    \
-                }                                                                                         \
-            }                                                                                             \
-            _Pragma("unroll") for (; sl_ < (nslots_); ++sl_) slot_fn_(sl_);                               \
+            float t0, t1, t2, t3;                                                                         \
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(i_[0]), "v"(w_[0]), "v"(a_[0]));     \
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(i_[1]), "v"(w_[1]), "v"(a_[1]));     \
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t2) : "v"(i_[2]), "v"(w_[2]), "v"(a_[2]));     \
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(i_[3]), "v"(w_[3]), "v"(a_[3]));     \
+            a_[0] = t0; a_[1] = t1; a_[2] = t2; a_[3] = t3;                                               \
+        }
+#else
+#define ACX_DW_MAC(a_, i_, w_) a_ += i_ * w_;
+#endif
+        // opaque re-definition of acc pins the FMAs in place (plain arithmetic is otherwise sunk below later reads)
+#define ACX_DW_PIN asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]));
+#define ACX_DW_FMA0(w_)                                                                                   \
+        {                                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 7; ++j)                                                 \
+            _Pragma("unroll") for (int kx = 0; kx <= j; ++kx) ACX_DW_MAC(acc[j - kx], iA[j], w_[kx])      \
+            ACX_DW_PIN                                                                                    \
+        }
+#define ACX_DW_FMA1(w_)                                                                                   \
+        {                                                                                                 \
+            _Pragma("unroll") for (int j = 7; j < 13; ++j)                                                \
+            _Pragma("unroll") for (int kx = j - 6; kx < 7; ++kx) ACX_DW_MAC(acc[j - kx], iB[j - 7], w_[kx]) \
+            ACX_DW_PIN                                                                                    \
         }
         // one asm statement per register set: ONE lgkmcnt wait, placed in front of the next batch of reads
 #define ACX_DW_TOUCH6(a_) asm volatile("" :: "v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]), "v"(a_[4]), "v"(a_[5]));
 #define ACX_DW_TOUCH7(a_) asm volatile("" :: "v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]), "v"(a_[4]), "v"(a_[5]), "v"(a_[6]));
-        // input row i_: current kernel row in wc_ (upper output row), previous one in wp_ (lower output row),
-        // the next one is prefetched into wn_
-#define ACX_DW_IROW(i_, wc_, wp_, wn_)                                                                    \
+        // LDS reads are SPREAD between the FMAs (sched_group_barrier: 1 ds_read, then a few VALU, repeated):
+        // eight waves bursting 14 reads each overflow the LDS queue and stall the issuing waves.
+#define ACX_DW_MIX(nread_, nvalu_)                                                                        \
+        _Pragma("unroll") for (int z = 0; z < (nread_); ++z) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
+            __builtin_amdgcn_sched_group_barrier(0x002, (nvalu_), 0);                                     \
+        }
+#define ACX_DW_KROW(ky_, wc_, wn_)   /* kernel row ky_ with weights wc_; prefetches row ky_+1 into wn_ */   \
         {                                                                                                 \
-            ACX_DW_ROWP(i_, pB_)                                                                          \
-            auto rdB_ = [&](int k) __attribute__((always_inline)) { iB[2 * k] = pB_[(7 + 2 * k) * 16]; iB[2 * k + 1] = pB_[(8 + 2 * k) * 16]; }; \
-            ACX_DW_UNIT(i_, wc_, wp_, iA, 0, 7, 3, rdB_)                                                  \
+            ACX_DW_READ_I1(ky_)                                                                           \
+            ACX_DW_FMA0(wc_)                                                                              \
+            ACX_DW_MIX(6, 9)                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                            \
             ACX_DW_TOUCH6(iB)                                                                             \
-            ACX_DW_ROWP(((i_) + 1 < 8 ? (i_) + 1 : 0), pA_)                                               \
-            const f32x2* const pW_ = wl2 + (((i_) + 1 < 7 ? (i_) + 1 : 0) * 7) * 16 + lw;                 \
-            auto rdA_ = [&](int k) __attribute__((always_inline)) {              /* slots 0..3: next input row, 4..7: next kernel row */  \
-                if (k < 3) { iA[2 * k] = pA_[(2 * k) * 16]; iA[2 * k + 1] = pA_[(2 * k + 1) * 16]; }       \
-                else if (k == 3) { iA[6] = pA_[6 * 16]; }                                                 \
-                else if (k < 7) { wn_[2 * (k - 4)] = pW_[(2 * (k - 4)) * 16]; wn_[2 * (k - 4) + 1] = pW_[(2 * (k - 4) + 1) * 16]; } \
-                else { wn_[6] = pW_[6 * 16]; }                                                            \
-            };                                                                                            \
-            ACX_DW_UNIT(i_, wc_, wp_, iB, 7, 13, ((i_) + 1 < 7 ? 8 : ((i_) + 1 < 8 ? 4 : 0)), rdA_)       \
+            if ((ky_) + 1 < 7) { ACX_DW_READ_W(wn_, (ky_) + 1) ACX_DW_READ_I0((ky_) + 1) }                \
+            ACX_DW_FMA1(wc_)                                                                              \
+            if ((ky_) + 1 < 7) { ACX_DW_MIX(14, 3) }                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                            \
-            if ((i_) + 1 < 7) { ACX_DW_TOUCH7(wn_) }                                                      \
-            if ((i_) + 1 < 8) { ACX_DW_TOUCH7(iA) }                                                       \
+            if ((ky_) + 1 < 7) { ACX_DW_TOUCH7(wn_) ACX_DW_TOUCH7(iA) }                                   \
         }
         ACX_DW_READ_W(wA, 0)
         ACX_DW_READ_I0(0)
 #ifndef ACX_LAB_DW_NOFMA
-        ACX_DW_IROW(0, wA, wC, wB) ACX_DW_IROW(1, wB, wA, wC) ACX_DW_IROW(2, wC, wB, wA) ACX_DW_IROW(3, wA, wC, wB)
-        ACX_DW_IROW(4, wB, wA, wC) ACX_DW_IROW(5, wC, wB, wA) ACX_DW_IROW(6, wA, wC, wB) ACX_DW_IROW(7, wB, wA, wC)
+        ACX_DW_KROW(0, wA, wB) ACX_DW_KROW(1, wB, wA) ACX_DW_KROW(2, wA, wB) ACX_DW_KROW(3, wB, wA)
+        ACX_DW_KROW(4, wA, wB) ACX_DW_KROW(5, wB, wA) ACX_DW_KROW(6, wA, wB)
 #endif
 #undef ACX_DW_ROWP
 #undef ACX_DW_READ_W
 #undef ACX_DW_READ_I0
 #undef ACX_DW_READ_I1
-#undef ACX_DW_PKFMA
-#undef ACX_DW_UNIT
+#undef ACX_DW_PIN
+#undef ACX_DW_MAC
+#undef ACX_DW_FMA0
+#undef ACX_DW_FMA1
 #undef ACX_DW_TOUCH6
 #undef ACX_DW_TOUCH7
-#undef ACX_DW_IROW
+#undef ACX_DW_KROW
+#undef ACX_DW_MIX
         ACX_STAMP(ts1)
         __builtin_amdgcn_sched_barrier(0);
         ACX_STAMP(ts2)
@@ -321,17 +276,11 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
 #endif
         }
 #pragma unroll
-        for (int i = 0; i < Cfg::WT; ++i) { so0[i] = a0[i]; so1[i] = a1[i]; }
-        {
-            ACX_DW_VROW(h0 + 2 * rp, n0_, r0_, ok0_)
-            ACX_DW_VROW(h0 + 2 * rp + 1, n1_, r1_, ok1_)
-            yp0 = ok0_ ? yb + (long long)(n0_ * H + r0_) * row_elems : nullptr;
-            yp1 = ok1_ ? yb + (long long)(n1_ * H + r1_) * row_elems : nullptr;
-        }
+        for (int i = 0; i < Cfg::WT; ++i) so[i] = acc[i];
+        yp_prev = (h0 + r < H) ? yb + (long long)(h0 + r) * row_elems : nullptr;
     }
     ACX_DW_FLUSH
 #undef ACX_DW_FLUSH
-#undef ACX_DW_FLUSH1
 #ifdef ACX_LAB_DW_STAMP
     if ((tid & 63) == 0) {
         for (int i = 0; i < 5; ++i) atomicAdd(&acx_dw_stamps[i], acc_s[i]);
@@ -339,11 +288,8 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
     }
 #endif
 #undef ACX_DW_LOAD_FAST
-#undef ACX_DW_VROW
 #undef ACX_DW_LOAD_EDGE
-#undef ACX_DW_LOAD_EDGE_TO
 #undef ACX_DW_STORE
-#undef ACX_DW_STORE_FROM
 }
 
 // Per-row LayerNorm statistics over C channels (biased variance, eps inside the sqrt --
@@ -473,16 +419,6 @@ int launch_layernorm_rows_bf16(acx_ctx* c, const float* x, void* out, int64_t M,
 
 template <int TW, int TH>
 static int launch_dw_cfg(const BlockW& w, int C, const float* x, float* y, int B, int H, int W, hipStream_t s) {
-    // exactness of v / (H + 3) by multiply-high needs (stacked rows) * (H + 3) < 2^32: longer batches in chunks
-    const long long max_b = (0xffffffffll / (H + 3)) / (H + 3);
-    if (B > max_b) {
-        for (long long b0 = 0; b0 < B; b0 += max_b) {
-            const int nb = (int)((B - b0) < max_b ? (B - b0) : max_b);
-            const long long off = b0 * (long long)H * W * C;
-            ACX_TRY((launch_dw_cfg<TW, TH>(w, C, x + off, y + off, nb, H, W, s)));
-        }
-        return ACX_OK;
-    }
     using Cfg = DwCfg<TW, TH>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -490,21 +426,22 @@ static int launch_dw_cfg(const BlockW& w, int C, const float* x, float* y, int B
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::kLdsBytes));
         attr_set = true;
     }
-    const int Hv = B * (H + 3) - 3;                    // stacked rows (no gap after the last clip)
-    const int tiles_w = W / TW, tiles_h = (Hv + TH - 1) / TH;
-    const long long columns = (long long)tiles_w * (C / kDwSlice);
-    // Workgroups = (column strips x channel slices) x row segments of the stacked image.  Two workgroups are
-    // resident per CU (512 slots): ONE round of equal segments -- every further round pays the ring prologue
-    // and the store drain again, and a fractional round idles the chip for a whole workgroup life.
-#ifndef ACX_LAB_DW_WGS
-#define ACX_LAB_DW_WGS 512   // diagnostic override (tools/dw_lab.hip): target number of workgroups
-#endif
-    int n_seg = (int)(ACX_LAB_DW_WGS / columns);
+    const int tiles_w = W / TW, tiles_h = (H + TH - 1) / TH;
+    const long long columns = (long long)B * tiles_w * (C / kDwSlice);
+    // Workgroups = columns x row segments.  Two workgroups are resident per CU (512 slots): aim at a whole
+    // number of rounds (3 x 512) -- a fractional last round idles half the chip for a whole workgroup life
+    // (measured 4.5 rounds = 5) -- with segments of at least 2 row tiles to amortise the ring prologue.
+    // (stage 2, 768 columns: ONE segment of 4 tiles per workgroup beats two of 2 -- 61 vs 73 us in tools/dw_lab --
+    //  although 768 workgroups are only 1.5 rounds: the ring prologue is the larger cost)
+    int n_seg = columns >= 768 ? 1 : (int)((1536 + columns / 2) / columns);
     if (n_seg > tiles_h / 2) n_seg = tiles_h / 2;
     if (n_seg < 1) n_seg = 1;
+#ifdef ACX_LAB_DW_NSEG       // diagnostic (tools/dw_lab.hip): force the number of row segments
+    n_seg = ACX_LAB_DW_NSEG > tiles_h ? tiles_h : ACX_LAB_DW_NSEG;
+#endif
     const long long blocks = columns * n_seg;
     dwconv7_kernel<TW, TH><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(
-        x, y, w.dw, w.dwb, B, H, W, C, tiles_w, tiles_h, n_seg, (unsigned)(0x100000000ull / (unsigned)(H + 3)) + 1u);
+        x, y, w.dw, w.dwb, H, W, C, tiles_w, tiles_h, n_seg);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
