@@ -105,6 +105,27 @@ def test_dwconv_and_ln_stats(ctx, taps, synth_sd, s):
     assert maxdiff(ln.view(B, H, W, C), taps["s%d.b0.ln" % s]) < LAYER_TOL
 
 
+# The depthwise kernel streams the whole batch as ONE stacked image (clip, 3 zero rows, clip, ...) in row tiles of
+# 8 / 8 / 16 / 32 rows: heights around the tile sizes, heights below the 7-row window, batches whose stacked height is
+# not a multiple of anything, and a batch long enough for every workgroup to cross several clip boundaries.
+@pytest.mark.parametrize("s,B,H", [(0, 1, 1), (0, 3, 5), (0, 2, 8), (0, 5, 13), (1, 1, 2), (1, 7, 9), (1, 2, 126),
+                                   (2, 1, 3), (2, 9, 16), (2, 4, 17), (2, 33, 5), (3, 1, 1), (3, 2, 29), (3, 70, 31),
+                                   (3, 3, 32), (3, 5, 33), (3, 6, 94)])
+def test_dwconv_shapes_vs_torch(ctx, synth_sd, s, B, H):
+    C, W = DIMS[s], 56 >> s
+    g = torch.Generator().manual_seed(100 * s + 7 * B + H)
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    x[0, 0, 0, :] = 3.0                      # corners: catch a shifted or wrapped window
+    x[-1, -1, -1, :] = -2.0
+    y = torch.full_like(x, float("nan"))
+    _ffi.check(_ffi.lib().acx_dwconv7(ctx.handle, s, 1, _ffi.ptr(x), _ffi.ptr(y), None, B, H, W, sp()))
+    wt = synth_sd["stages.%d.1.dwconv.weight" % s].cuda()
+    bias = synth_sd["stages.%d.1.dwconv.bias" % s].cuda()
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), padding=3, groups=C)
+    assert bool(torch.isfinite(y).all())
+    assert maxdiff(nchw(y), ref) < LAYER_TOL
+
+
 @pytest.mark.parametrize("s", [0, 1, 2, 3])
 def test_block(ctx, taps, s):
     x = nhwc(taps["ds%d" % s])
