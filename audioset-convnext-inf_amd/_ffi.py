@@ -107,7 +107,13 @@ class Context:
             lib().acx_destroy(self._h)
             self._h = _vp()
 
-    __del__ = close
+    def __del__(self):
+        # at interpreter shutdown the module globals (lib, _vp) may already be gone: the process is about to
+        # release the device anyway
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     @property
     def handle(self):

@@ -11,7 +11,11 @@ ProfScope::~ProfScope() {}
 }
 int main() {
     const long long P0 = 64LL * 252 * 56, P1 = P0 / 4;
-    struct S { int C; long long M; } shapes[] = {{96, P0}, {192, P1}};
+    struct S { int C; long long M; } shapes[] = {{96, P0}, {192, P1}
+#ifdef ACX_FSLAB_MALL     // whole rounds of 512 workgroups: 13, 3 and 1 -- does a cache-resident activation set run faster per round?
+        , {96, 512LL * 128 * 13}, {96, 512LL * 128 * 3}, {96, 512LL * 128}, {192, 512LL * 128 * 3}, {192, 512LL * 128}
+#endif
+    };
     float *y, *x, *b1, *b2; uint16_t* w;
     hipMalloc(&y, P0 * 96 * 4); hipMalloc(&x, P0 * 96 * 4); hipMalloc(&w, (size_t)4 * 192 * 192 * 2 * 4);
     hipMalloc(&b1, 4 * 192 * 4); hipMalloc(&b2, 192 * 4);
@@ -44,7 +48,7 @@ int main() {
             ms = t < ms ? t : ms;
         }
         double tf = 4.0 * s.M * s.C * 4 * s.C / (ms * 1e-3) / 1e12;
-        printf("fused-split C=%-4d M=%-8lld %8.1f us  %6.1f TF fp32-equivalent (%4.1f%% of 833)\n", s.C, s.M, ms * 1e3, tf, 100 * tf / 833.3);
+        printf("fused-split C=%-4d M=%-8lld %8.1f us  %6.1f TF fp32-equivalent (%4.1f%% of 833)  %6.2f us per round of 512 workgroups\n", s.C, s.M, ms * 1e3, tf, 100 * tf / 833.3, ms * 1e3 / (s.M / (512.0 * 128)));
 #ifdef ACX_FSLAB_STAMP
         unsigned long long st[8];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(acx::acx_fs_stamps), sizeof(st));
