@@ -174,7 +174,9 @@ int launch_gemm_split(acx_ctx* c, const GemmSplitArgs& a, hipStream_t s);
 bool mlp_fused_supported(int C);
 // x += MLP(LN(y)) for one block, hidden activation kept in registers (mlp_fused.hip)
 int launch_mlp_fused(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s);
-int launch_mlp_fused_split(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s);
+// ln_out != nullptr: do not write x; write LayerNorm(x_new) as S16 rows (the downsample GEMM's operand) there instead
+int launch_mlp_fused_split(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
+                           void* ln_out = nullptr);
 int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
                      hipStream_t s);
 int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, int W, int C, hipStream_t s);

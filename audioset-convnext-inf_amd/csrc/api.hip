@@ -407,14 +407,21 @@ static int run_mlp_split(acx_ctx* c, const BlockW& bw, int C, float* y, float* x
     return launch_gemm_split(c, g2, st);
 }
 
+// True when the last block of stage s can hand the downsample conv its LayerNorm'ed S16 operand directly
+// (fused split MLP kernel, LNOUT epilogue): x of that stage is then NOT updated by its last block.
+static bool block_can_emit_ln(const acx_ctx* c, int s) {
+    return s < 3 && c->precision == ACX_PREC_F32_SPLIT && c->use_fused_mlp && mlp_fused_supported(kDims[s]);
+}
+
 static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden, float* stats, int B, int H, int Wd,
-                     hipStream_t st) {
+                     hipStream_t st, void* ln_out = nullptr) {
     const int C = kDims[s];
     const BlockW& bw = c->blocks[s][j];
     const int64_t M = (int64_t)B * H * Wd;
     if (c->precision == ACX_PREC_F32_SPLIT) {
         ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
-        if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused_split(c, bw, C, y, x, M, st);
+        if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused_split(c, bw, C, y, x, M, st, ln_out);
+        if (ln_out) ACX_FAIL(ACX_ERR_STATE, "run_block: LayerNorm output requested from a two-GEMM stage");
         return run_mlp_split(c, bw, C, y, x, hidden, M, st);
     }
     if (c->precision == ACX_PREC_BF16) {
@@ -437,11 +444,12 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     return ACX_OK;
 }
 
+// have_ln: xnorm already holds the normalised S16 rows (written by the last block of the previous stage)
 static int run_downsample(acx_ctx* c, int i, const float* x, float* out, float* xnorm, int B, int H, int Wd,
-                          hipStream_t st) {
+                          hipStream_t st, bool have_ln = false) {
     const int Ci = kDims[i - 1], Co = kDims[i];
     if (c->precision == ACX_PREC_F32_SPLIT) {
-        ACX_TRY(launch_layernorm_rows_split(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
+        if (!have_ln) ACX_TRY(launch_layernorm_rows_split(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
         GemmSplitArgs g{};
         g.A = xnorm; g.Wt = c->down[i].ws; g.bias = c->down[i].b; g.out = out;
         g.gather = 1; g.H = H; g.W = Wd; g.C = Ci; g.Ho = H / 2; g.Wo = Wd / 2;
@@ -600,8 +608,13 @@ static int forward_one(acx_ctx* c, const float* wav, int B, int64_t L, int mode,
     ACX_TRY(launch_logmel(c, wav, B, L, p.T, feat, true, st));
     ACX_TRY(launch_stem(c, feat, B, p.T, p.Hs[0], x[0], st));
     for (int s = 0; s < 4; ++s) {
-        if (s > 0) ACX_TRY(run_downsample(c, s, x[s - 1], x[s], y, B, p.Hs[s - 1], p.Ws[s - 1], st));
-        for (int j = 0; j < kDepths[s]; ++j) ACX_TRY(run_block(c, s, j, x[s], y, hidden, stats, B, p.Hs[s], p.Ws[s], st));
+        if (s > 0) ACX_TRY(run_downsample(c, s, x[s - 1], x[s], y, B, p.Hs[s - 1], p.Ws[s - 1], st, block_can_emit_ln(c, s - 1)));
+        for (int j = 0; j < kDepths[s]; ++j) {
+            // the last block of stages 0-1 writes LayerNorm(x) in S16 form into y (the downsample's operand buffer)
+            // instead of x: nothing else reads that x (convnext.py:270-273)
+            void* ln_out = (j == kDepths[s] - 1 && block_can_emit_ln(c, s)) ? (void*)y : nullptr;
+            ACX_TRY(run_block(c, s, j, x[s], y, hidden, stats, B, p.Hs[s], p.Ws[s], st, ln_out));
+        }
     }
     if (mode == ACX_MODE_FRAME) return launch_nhwc_to_nchw(c, x[3], out0, B, p.Hs[3], p.Ws[3], kDims[3], st);
     if (mode == ACX_MODE_SCENE) return launch_pool_head(c, x[3], B, p.Hs[3], out0, nullptr, nullptr, st);

@@ -60,10 +60,11 @@ struct FusedSCfg {
     __device__ static int swz1(int row) { return (C == 96) ? ((row >> 1) & 7) : (row & 15); }
 };
 
-template <int C>
+template <int C, bool LNOUT>
 __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel(
     const float* __restrict__ y, float* __restrict__ x, const char* __restrict__ wpack /*[chunks][256*C bytes]*/,
-    const float* __restrict__ b1, const float* __restrict__ b2, long long M, float sinv1, float sinv2) {
+    const float* __restrict__ b1, const float* __restrict__ b2, long long M, float sinv1, float sinv2,
+    char* __restrict__ ln_out /* LNOUT: (M, C) S16 rows of LayerNorm(x_new) x 2^11, written INSTEAD of x */) {
     using Cfg = FusedSCfg<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w1buf = smem;                                                  // [kRing][kHalfBytes]  rows = hidden
@@ -372,7 +373,62 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
         return;
     }
 #endif
-    if (valid) {
+    if constexpr (LNOUT) {
+        // Last block of a stage in the full forward: the only reader of the new x is the LayerNorm in front of the
+        // downsample conv (convnext.py:230-235 -- no skip connection leaves the stage), and this wave holds whole
+        // rows (a lane and its partner at lane ^ 32 hold all C channels of one pixel).  So normalise here and
+        // write the S16 operand of the downsample GEMM (same form as rowstats_kernel<.,3>: two-pass statistics,
+        // biased variance, eps 1e-6, x 2^11, blocks [8 hi][8 lo]) in place of x: one tensor pass less on each
+        // side and no LayerNorm launch.  ln_out may alias y: a workgroup reads its own rows of y at the start only.
+        const float* xp = x + mrow * C + 4 * hh;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < C / 32; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 32 * t + 8 * q;
+                const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
+                const float4 v = *reinterpret_cast<const float4*>(xp + c);
+                acc[t][4 * q + 0] = v.x + fmaf(acc[t][4 * q + 0], sinv2, bb.x);
+                acc[t][4 * q + 1] = v.y + fmaf(acc[t][4 * q + 1], sinv2, bb.y);
+                acc[t][4 * q + 2] = v.z + fmaf(acc[t][4 * q + 2], sinv2, bb.z);
+                acc[t][4 * q + 3] = v.w + fmaf(acc[t][4 * q + 3], sinv2, bb.w);
+                sum += (acc[t][4 * q + 0] + acc[t][4 * q + 1]) + (acc[t][4 * q + 2] + acc[t][4 * q + 3]);
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / C);
+        float d = 0.f;
+#pragma unroll
+        for (int t = 0; t < C / 32; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float u = acc[t][r] - mean; d = fmaf(u, u, d); }
+        d += __shfl_xor(d, 32);
+        const float sc = kSplitLnScale / sqrtf(d * (1.0f / C) + 1e-6f);
+        if (valid) {
+            char* op = ln_out + mrow * (long long)(C * 4) + 8 * hh;
+#pragma unroll
+            for (int t = 0; t < C / 32; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned uhi[2], ulo[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        f32x2 v;
+                        v.x = (acc[t][4 * q + 2 * e] - mean) * sc; v.y = (acc[t][4 * q + 2 * e + 1] - mean) * sc;
+                        const h2 h = __builtin_convertvector(v, h2);
+                        const f32x2 back = __builtin_convertvector(h, f32x2);
+                        const h2 l = __builtin_convertvector(v - back, h2);
+                        uhi[e] = __builtin_bit_cast(unsigned, h);
+                        ulo[e] = __builtin_bit_cast(unsigned, l);
+                    }
+                    char* blk = op + (4 * t + q) * 32;          // channels 32t + 8q .. +7: this lane the half 4hh .. +3
+                    *reinterpret_cast<uint2*>(blk) = uint2{uhi[0], uhi[1]};
+                    *reinterpret_cast<uint2*>(blk + 16) = uint2{ulo[0], ulo[1]};
+                }
+            }
+        }
+    } else if (valid) {
         float* xp = x + mrow * C + 4 * hh;
 #pragma unroll
         for (int t = 0; t < C / 32; ++t) {
@@ -405,28 +461,29 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
 #endif
 }
 
-template <int C>
-static int launch_fused_s_cfg(const BlockW& w, const float* y, float* x, long long M, hipStream_t s) {
+template <int C, bool LNOUT>
+static int launch_fused_s_cfg(const BlockW& w, const float* y, float* x, long long M, void* ln_out, hipStream_t s) {
     using Cfg = FusedSCfg<C>;
     static bool attr_set = false;
     if (!attr_set) {
-        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_split_kernel<C>),
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_split_kernel<C, LNOUT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::kLdsBytes));
         attr_set = true;
     }
     const long long blocks = (M + Cfg::kPix - 1) / Cfg::kPix;
-    mlp_fused_split_kernel<C><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(
+    mlp_fused_split_kernel<C, LNOUT><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(
         y, x, reinterpret_cast<const char*>(w.wpack_s), w.b1, w.b2, M, 1.0f / (kSplitLnScale * w.w1s_scale),
-        1.0f / (kSplitHiddenScale * w.w2s_scale));
+        1.0f / (kSplitHiddenScale * w.w2s_scale), reinterpret_cast<char*>(ln_out));
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
 
-int launch_mlp_fused_split(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s) {
+int launch_mlp_fused_split(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
+                           void* ln_out) {
     if (!w.wpack_s) ACX_FAIL(ACX_ERR_STATE, "fused split MLP: chunk-major S16 weights were not packed for C=%d", C);
     ProfScope ps(c, ACX_K_MLP_FUSED, s);
-    if (C == 96) return launch_fused_s_cfg<96>(w, y, x, M, s);
-    if (C == 192) return launch_fused_s_cfg<192>(w, y, x, M, s);
+    if (C == 96) return ln_out ? launch_fused_s_cfg<96, true>(w, y, x, M, ln_out, s) : launch_fused_s_cfg<96, false>(w, y, x, M, nullptr, s);
+    if (C == 192) return ln_out ? launch_fused_s_cfg<192, true>(w, y, x, M, ln_out, s) : launch_fused_s_cfg<192, false>(w, y, x, M, nullptr, s);
     ACX_FAIL(ACX_ERR_SHAPE, "fused split MLP: unsupported channel count %d", C);
 }
 
