@@ -4,10 +4,14 @@
 // in : bn0'd log-mel (B,T,224) fp32.  The stem's zero padding is applied AFTER bn0
 //      (convnext.py:304-306 then :690), so padded time rows are literal zeros here.
 // out: NHWC (B,H0,56,96), H0 = (T+8-4)/4+1.  Output row h reads time rows 4h-4 .. 4h-1.
-// 16->96 is too thin for MFMA: VALU patch-embed, 32 lanes x 3 channels per pixel (2 pixels per
-// wave64; lane l owns channels l, l+32, l+64 so that every store instruction writes 128 contiguous bytes
-// per pixel), LayerNorm statistics by xor-shuffles inside each 32-lane half.  HBM-bound:
-// 0.90 MB in + 5.42 MB out per 10 s clip.
+// 16->96 is too thin for MFMA: VALU patch-embed.  A workgroup takes whole output rows (b, h): the 4 x 224 input
+// floats of the row are fetched ONCE, coalesced, into LDS (the first version let every lane of a pixel load the
+// same 4 float4 itself: 64-lane broadcast loads keep the texture-address unit as busy as distinct ones, and it,
+// not HBM, set the pace -- 2.4 TB/s); each 32-lane group then walks 7 of the row's 56 pixels, 24 of its lanes
+// owning 4 consecutive channels each, so a pixel leaves as ONE 384-byte run of float4 stores.  LayerNorm
+// statistics by xor-shuffles inside the 32-lane group (idle lanes contribute zeros).  HBM-bound, and 86 % of
+// the bytes are writes: 0.90 MB in + 5.42 MB out per 10 s clip; 2.9 TB/s at B = 64 (keeping all seven pixels of a
+// group in registers to overlap their shuffle chains changes nothing: it is not latency).
 #include "acx_internal.h"
 
 namespace acx {
@@ -21,94 +25,89 @@ __device__ __forceinline__ float half_sum32(float v) {
     return v;
 }
 
-constexpr int kStemPix = 4;     // consecutive output pixels (same row) per 32-lane group per iteration: 16
-                                // independent 16-B loads in flight per lane instead of 4
+constexpr int kStemGroups = 8;                 // 32-lane groups per workgroup; 56 pixels / 8 = 7 pixels per group and row
+constexpr int kStemRowF4 = kMels / 4;          // 56 float4 per input row = one per output pixel
 
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, int T, int H0, long long ngroups,
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, int T, int H0, long long nrows,
                                                    const float* __restrict__ w /*[96][16]*/,
                                                    const float* __restrict__ bias, const float* __restrict__ lnw,
                                                    const float* __restrict__ lnb, float* __restrict__ out) {
-    const int l32 = threadIdx.x & 31;
-    const int sub = threadIdx.x >> 5;             // 8 pixel groups per block iteration
-    float wr[3][16], br[3], gw[3], gb[3];
+    __shared__ float4 patch[2][4][kStemRowF4];          // double-buffered: one barrier per row
+    const int tid = threadIdx.x;
+    const int l32 = tid & 31;
+    const int grp = tid >> 5;
+    const bool owner = l32 < 24;
+    const int ch = owner ? 4 * l32 : 92;                // idle lanes compute on valid addresses and are masked out
+    float wr[4][16], br[4], gw[4], gb[4];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int ch = l32 + 32 * c;
+    for (int c = 0; c < 4; ++c) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) wr[c][k] = w[ch * 16 + k];
-        br[c] = bias[ch];
-        gw[c] = lnw[ch];
-        gb[c] = lnb[ch];
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const float4 v = *reinterpret_cast<const float4*>(w + (ch + c) * 16 + 4 * k4);
+            wr[c][4 * k4 + 0] = v.x; wr[c][4 * k4 + 1] = v.y; wr[c][4 * k4 + 2] = v.z; wr[c][4 * k4 + 3] = v.w;
+        }
+        br[c] = bias[ch + c];
+        gw[c] = lnw[ch + c];
+        gb[c] = lnb[ch + c];
     }
-    constexpr int GPR = kStemW / kStemPix;        // groups per output row (14)
-    const long long stride = (long long)gridDim.x * 8;
-    const long long iters = (ngroups + stride - 1) / stride;      // uniform trip count (shuffles need full waves)
-    for (long long it = 0; it < iters; ++it) {
-        long long g = it * stride + (long long)blockIdx.x * 8 + sub;
-        const bool valid = g < ngroups;
-        if (!valid) g = ngroups - 1;
-        const int wg = (int)(g % GPR);
-        const long long bh = g / GPR;
-        const int h = (int)(bh % H0);
-        const long long b = bh / H0;
-        float4 xin[4][kStemPix];
+    const float keep = owner ? 1.0f : 0.0f;
+    // staging: thread i < 224 fetches float4 (ky = i / 56, w = i % 56) of the current row
+    const int sky = tid / kStemRowF4, sw = tid - sky * kStemRowF4;
+    const bool stager = tid < 4 * kStemRowF4;
+    auto fetch = [&](long long row) -> float4 {
+        const int h = (int)(row % H0);
+        const long long b = row / H0;
+        int t = 4 * h - 4 + sky;
+        const bool rok = stager && t >= 0 && t < T;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);           // clamped address, zeroed below (no branchy loads)
+        float4 v = *reinterpret_cast<const float4*>(in + (b * T + t) * kMels + 4 * (stager ? sw : 0));
+        if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        return v;
+    };
+    long long row = blockIdx.x;
+    if (row >= nrows) return;
+    float4 nxt = fetch(row);
+    int buf = 0;
+    for (; row < nrows; row += gridDim.x) {
+        if (stager) patch[buf][sky][sw] = nxt;
+        __syncthreads();                                // this row's patches visible; the other buffer is free again
+        const long long row_n = row + gridDim.x;
+        if (row_n < nrows) nxt = fetch(row_n);          // in flight under this row's arithmetic
+        float* orow = out + row * (long long)(kStemW * 96) + ch;
 #pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-            int t = 4 * h - 4 + ky;
-            const bool rok = t >= 0 && t < T;
-            t = t < 0 ? 0 : (t >= T ? T - 1 : t);              // clamped address, zeroed below (no branchy loads)
-            const float4* rp = reinterpret_cast<const float4*>(in + (b * T + t) * kMels + 4 * kStemPix * wg);
+        for (int i = 0; i < kStemW / kStemGroups; ++i) {
+            const int px = grp + kStemGroups * i;
+            float acc[4] = {br[0], br[1], br[2], br[3]};
 #pragma unroll
-            for (int px = 0; px < kStemPix; ++px) {
-                float4 v = rp[px];
-                if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                xin[ky][px] = v;
-            }
-        }
-        float acc[kStemPix][3];
+            for (int ky = 0; ky < 4; ++ky) {
+                const float4 p = patch[buf][ky][px];    // same address for the whole group: LDS broadcast
 #pragma unroll
-        for (int px = 0; px < kStemPix; ++px) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float a = br[c];
-#pragma unroll
-                for (int ky = 0; ky < 4; ++ky) {
-                    a = fmaf(xin[ky][px].x, wr[c][4 * ky + 0], a);
-                    a = fmaf(xin[ky][px].y, wr[c][4 * ky + 1], a);
-                    a = fmaf(xin[ky][px].z, wr[c][4 * ky + 2], a);
-                    a = fmaf(xin[ky][px].w, wr[c][4 * ky + 3], a);
+                for (int c = 0; c < 4; ++c) {
+                    acc[c] = fmaf(p.x, wr[c][4 * ky + 0], acc[c]);
+                    acc[c] = fmaf(p.y, wr[c][4 * ky + 1], acc[c]);
+                    acc[c] = fmaf(p.z, wr[c][4 * ky + 2], acc[c]);
+                    acc[c] = fmaf(p.w, wr[c][4 * ky + 3], acc[c]);
                 }
-                acc[px][c] = a;
             }
+            const float mean = half_sum32(((acc[0] + acc[1]) + (acc[2] + acc[3])) * keep) * (1.0f / 96.0f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] -= mean;
+            const float var = half_sum32(((acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3])) * keep) * (1.0f / 96.0f);
+            const float rstd = 1.0f / sqrtf(var + 1e-6f);
+            if (owner)
+                *reinterpret_cast<float4*>(orow + px * 96) =
+                    make_float4(fmaf(acc[0] * rstd, gw[0], gb[0]), fmaf(acc[1] * rstd, gw[1], gb[1]),
+                                fmaf(acc[2] * rstd, gw[2], gb[2]), fmaf(acc[3] * rstd, gw[3], gb[3]));
         }
-        float mean[kStemPix], var[kStemPix];
-#pragma unroll
-        for (int px = 0; px < kStemPix; ++px) mean[px] = half_sum32(acc[px][0] + acc[px][1] + acc[px][2]) * (1.0f / 96.0f);
-#pragma unroll
-        for (int px = 0; px < kStemPix; ++px) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[px][c] -= mean[px];
-            var[px] = half_sum32(acc[px][0] * acc[px][0] + acc[px][1] * acc[px][1] + acc[px][2] * acc[px][2]) * (1.0f / 96.0f);
-        }
-        if (valid) {
-            float* o = out + (g * kStemPix) * 96 + l32;
-#pragma unroll
-            for (int px = 0; px < kStemPix; ++px) {
-                const float rstd = 1.0f / sqrtf(var[px] + 1e-6f);
-                o[px * 96 + 0] = fmaf(acc[px][0] * rstd, gw[0], gb[0]);
-                o[px * 96 + 32] = fmaf(acc[px][1] * rstd, gw[1], gb[1]);
-                o[px * 96 + 64] = fmaf(acc[px][2] * rstd, gw[2], gb[2]);
-            }
-        }
+        buf ^= 1;
     }
 }
 
 int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, float* out, hipStream_t s) {
-    const long long ngroups = (long long)B * H0 * (kStemW / kStemPix);
-    long long blocks = (ngroups + 7) / 8;
-    if (blocks > 8192) blocks = 8192;
+    const long long nrows = (long long)B * H0;
+    long long blocks = nrows < 2048 ? nrows : 2048;     // 8 resident workgroups per CU, every workgroup walks ~8 rows at B = 64
     ProfScope ps(c, ACX_K_STEM, s);
-    stem_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, T, H0, ngroups, c->d_stem_w, c->d_stem_b,
+    stem_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, T, H0, nrows, c->d_stem_w, c->d_stem_b,
                                                               c->d_stem_lnw, c->d_stem_lnb, out);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
