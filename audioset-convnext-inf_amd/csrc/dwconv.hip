@@ -13,7 +13,7 @@
 
 namespace acx {
 
-constexpr int kDwSlice = 32;      // channels per workgroup (8 lanes x float4)
+constexpr int kDwSlice = 32;      // channels per workgroup (staged as 8 x float4, computed as 16 lanes x float2)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -25,8 +25,8 @@ __device__ unsigned long long acx_dw_stamps[8];
 #define ACX_STAMP(var)
 #endif
 
-// Streaming form: a workgroup owns (clip, 32-channel slice, column strip of TW pixels, segment of row tiles)
-// and walks DOWN the image.  An LDS ring of TH+6 input rows is kept; each step computes TH output rows from
+// Streaming form: a workgroup owns (32-channel slice, column strip of TW pixels, segment of row tiles of the
+// stacked batch) and walks DOWN the images.  An LDS ring of TH+6 input rows is kept; each step computes TH output rows from
 // the ring while the next TH input rows are already in flight to registers (issued before the FMAs, written
 // into the ring slots of the TH oldest rows after them), so every input row is fetched once per strip
 // (the first tile-only version re-read its 6 halo rows per tile: FETCH_SIZE 1.93x the algorithmic bytes,
@@ -35,7 +35,7 @@ template <int TW, int TH>
 struct DwCfg {
     static constexpr int WT = 7;
     static constexpr int kStrips = TW / WT;
-    static constexpr int kThreads = kStrips * 8 * TH;
+    static constexpr int kThreads = kStrips * 8 * TH;             // = strips x 16 lanes x TH/2 row pairs
     static constexpr int kCols = TW + 6;
     static constexpr int kRing = TH + 6;
     static constexpr int kRowF4 = kCols * 8;                      // float4 per ring row
