@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libacx.so")
+LIB_PATH = os.environ.get("ACX_LIB") or os.path.join(_HERE, "libacx.so")     # ACX_LIB: diagnostic builds (tools/)
 
 OK = 0
 MODE_LOGITS, MODE_SCENE, MODE_FRAME = 0, 1, 2

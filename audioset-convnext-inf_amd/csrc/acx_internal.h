@@ -61,6 +61,7 @@ struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layou
     uint16_t* w2s = nullptr; // split mode: gamma * pwconv2 in S16 form, scaled by w2s_scale
     uint16_t* wpack_s = nullptr; // split mode, C = 96/192: chunk-major [W1c | W2c] S16 image (mlp_fused_split.hip)
     float w1s_scale = 1.f, w2s_scale = 1.f;
+    float hid_scale = 1.f;   // split mode: power-of-two scale of the S16 hidden activation (GELU output)
 };
 
 struct DownW {           // downsample_layers[i], i>=1 (convnext.py:230-235)
@@ -162,11 +163,13 @@ struct GemmBf16Args {
 int launch_gemm_bf16(acx_ctx* c, const GemmBf16Args& a, hipStream_t s);
 // fp32 operands as two fp16 halves (gemm_split.hip): A, Wt in S16 form; EPI_GELU writes S16, the others fp32
 constexpr float kSplitLnScale = 2048.0f;      // LayerNorm rows: |LN(y)| <= sqrt(C-1) < 28 -> < 2^15.8
-constexpr float kSplitHiddenScale = 16.0f;    // GELU output, clamped to the fp16 range after scaling
+// The GELU output (hidden activation) is scaled per block by BlockW::hid_scale, a power of two chosen at acx_finalize
+// from a rigorous bound on |pwconv1 output| (api.hip, hidden_scale_for): the fp16 range cannot be exceeded.
 int launch_layernorm_rows_split(acx_ctx* c, const float* x, void* out, int64_t M, int C, hipStream_t s);
 struct GemmSplitArgs {
     const void* A; const void* Wt; const float* bias; void* out; const float* resid;
     int64_t M; int N; int K; float sinv;
+    float hscale;            // EPI_GELU: power-of-two scale of the S16 output
     int gather; int H, W, C, Ho, Wo;
     int epi; int cls;
 };

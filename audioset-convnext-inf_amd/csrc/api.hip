@@ -132,6 +132,24 @@ static float s16_scale(const std::vector<float>& w) {
     return std::ldexp(1.0f, 14 - std::ilogb(mx));
 }
 
+// Power-of-two scale of the S16 hidden activation of one block.  The GEMM input is z = LayerNorm(y) without affine
+// (the affine is folded into w1 / b1): ||z||_2 <= sqrt(C), so |h_n| = |w1_n . z + b1_n| <= ||w1_n||_2 sqrt(C) + |b1_n|
+// (Cauchy-Schwarz) and |GELU(h)| <= |h|.  The scale puts that bound below the largest fp16 number: the clamp in
+// gelu_piece3 (split_math.h) cannot be reached, whatever the input.  Typical weights give 2^10..2^11; the absolute
+// resolution of a stored value is 2^-25 / scale (fp16 subnormal spacing of the lo half).
+static float hidden_scale_for(const std::vector<float>& w1, const std::vector<float>& b1, int N, int C) {
+    double worst = 0.0;
+    for (int n = 0; n < N; ++n) {
+        double ss = 0.0;
+        for (int k = 0; k < C; ++k) ss += (double)w1[(size_t)n * C + k] * w1[(size_t)n * C + k];
+        worst = std::fmax(worst, std::sqrt(ss) * std::sqrt((double)C) + std::fabs((double)b1[n]));
+    }
+    if (!(worst > 0.0) || !std::isfinite(worst)) return 1.f;
+    int e = (int)std::floor(std::log2(65000.0 / worst));
+    e = e > 12 ? 12 : (e < -40 ? -40 : e);
+    return std::ldexp(1.0f, e);
+}
+
 static void free_device(acx_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
@@ -294,6 +312,7 @@ static int finalize_impl(acx_ctx* c) {
             if (c->precision == ACX_PREC_F32_SPLIT) {
                 bw.w1s_scale = s16_scale(f1);
                 bw.w2s_scale = s16_scale(f2);
+                bw.hid_scale = hidden_scale_for(f1, fb1, 4 * C, C);
                 const std::vector<uint16_t> h1 = s16_rows(f1, 4 * C, C, bw.w1s_scale);
                 ACX_TRY(upload(c, h1, &bw.w1s));
                 ACX_TRY(upload(c, s16_rows(f2, C, 4 * C, bw.w2s_scale), &bw.w2s));
@@ -399,11 +418,11 @@ static int run_mlp_split(acx_ctx* c, const BlockW& bw, int C, float* y, float* x
     ACX_TRY(launch_layernorm_rows_split(c, y, y, M, C, st));
     GemmSplitArgs g1{};
     g1.A = y; g1.Wt = bw.w1s; g1.bias = bw.b1; g1.out = hidden; g1.M = M; g1.N = 4 * C; g1.K = C;
-    g1.sinv = 1.0f / (kSplitLnScale * bw.w1s_scale); g1.epi = EPI_GELU; g1.cls = ACX_K_PW1;
+    g1.sinv = 1.0f / (kSplitLnScale * bw.w1s_scale); g1.hscale = bw.hid_scale; g1.epi = EPI_GELU; g1.cls = ACX_K_PW1;
     ACX_TRY(launch_gemm_split(c, g1, st));
     GemmSplitArgs g2{};
     g2.A = hidden; g2.Wt = bw.w2s; g2.bias = bw.b2; g2.out = x; g2.resid = x; g2.M = M; g2.N = C; g2.K = 4 * C;
-    g2.sinv = 1.0f / (kSplitHiddenScale * bw.w2s_scale); g2.epi = EPI_RESID; g2.cls = ACX_K_PW2;
+    g2.sinv = 1.0f / (bw.hid_scale * bw.w2s_scale); g2.epi = EPI_RESID; g2.cls = ACX_K_PW2;
     return launch_gemm_split(c, g2, st);
 }
 

@@ -36,6 +36,7 @@ struct GemmSParams {
     const char* A; const char* Wt; const float* bias; void* out; const float* resid;
     long long M; int N; int K;
     float sinv;                // 1 / (scale of A * scale of Wt)
+    float hscale;              // EPI 1: scale of the S16 result (power of two)
     int H, W, C, Ho, Wo;       // gather mode: A is (B,H,W,C) S16 rows; row m = (b,ho,wo), k = (dy*2+dx)*C + c
     int tiles_n;
 };
@@ -43,6 +44,13 @@ struct GemmSParams {
 __device__ __forceinline__ void lds_dma16_s(const char* gsrc, char* lds_wave_base) {
 #ifdef ACX_SLAB_NO_DMA      // diagnostic: no operand traffic at all (LDS holds garbage)
     return;
+#endif
+#ifdef ACX_DBG_SYNC_STAGE   // diagnostic: register staging (global_load -> ds_write_b128) instead of LDS-DMA, same layout
+    {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(gsrc);
+        *reinterpret_cast<f32x4*>(lds_wave_base + 16 * (threadIdx.x & 63)) = v;
+        return;
+    }
 #endif
 #ifdef ACX_DBG_PLAIN_LOADS  // diagnostic: the same bytes by ordinary 16-B loads into registers (LDS keeps garbage)
     {
@@ -340,11 +348,11 @@ typedef float dbg_f4 __attribute__((ext_vector_type(4)));
 #endif
     const float sinv = p.sinv;
     if (EPI == 1) {
-        GeluConsts gk;          // GELU of v = a * sinv, result x kSplitHiddenScale (see split_math.h)
+        GeluConsts gk;          // GELU of v = a * sinv, result x p.hscale (see split_math.h)
         gk.ps = 0.3275911f * 0.70710678f * sinv;
         gk.cq = 0.84932180f * sinv;       // sqrt(log2(e) / 2): exp(-v^2 / 2) = exp2(-(cq a)^2)
-        gk.ca = -0.5f * sinv * kSplitHiddenScale;
-        gk.cb = sinv * kSplitHiddenScale;
+        gk.ca = -0.5f * sinv * p.hscale;
+        gk.cb = sinv * p.hscale;
         const float binv = 1.0f / sinv;     // a power of two
         // ---- GELU epilogue, D = W A^T: lane = row m, registers r = 4q+e hold n = 8q + 4hh + e ------------------
         // One S16 block (8 n) = [hi x8][lo x8] is shared by the lane pair (l31, hh=0/1): after a permlane32 swap
@@ -422,7 +430,13 @@ static int launch_s_cfg(const GemmSParams& p0, hipStream_t s) {
     const long long tiles_m = (p.M + kBM - 1) / kBM;
     const long long blocks = tiles_m * p.tiles_n;
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: grid too large");
+#if defined(ACX_DBG_LDS120)      // diagnostic: one workgroup per CU and no room for a 48-KB neighbour
+    constexpr size_t lds = 120 * 1024;
+#elif defined(ACX_DBG_LDS80)     // diagnostic: two workgroups fill the CU's LDS
+    constexpr size_t lds = 80 * 1024;
+#else
     constexpr size_t lds = (size_t)2 * (kBM + BN) * kSRowBytes;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER>),
@@ -466,7 +480,7 @@ int launch_gemm_split(acx_ctx* c, const GemmSplitArgs& a, hipStream_t s) {
     if (a.M <= 0) return ACX_OK;
     GemmSParams p;
     p.A = reinterpret_cast<const char*>(a.A); p.Wt = reinterpret_cast<const char*>(a.Wt); p.bias = a.bias;
-    p.out = a.out; p.resid = a.resid; p.M = a.M; p.N = a.N; p.K = a.K; p.sinv = a.sinv;
+    p.out = a.out; p.resid = a.resid; p.M = a.M; p.N = a.N; p.K = a.K; p.sinv = a.sinv; p.hscale = a.hscale;
     p.H = a.H; p.W = a.W; p.C = a.C; p.Ho = a.Ho; p.Wo = a.Wo; p.tiles_n = 0;
     ProfScope ps(c, a.cls, s);
     if (a.gather) {

@@ -63,7 +63,7 @@ struct FusedSCfg {
 template <int C, bool LNOUT>
 __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel(
     const float* __restrict__ y, float* __restrict__ x, const char* __restrict__ wpack /*[chunks][256*C bytes]*/,
-    const float* __restrict__ b1, const float* __restrict__ b2, long long M, float sinv1, float sinv2,
+    const float* __restrict__ b1, const float* __restrict__ b2, long long M, float sinv1, float sinv2, float hscale,
     char* __restrict__ ln_out /* LNOUT: (M, C) S16 rows of LayerNorm(x_new) x 2^11, written INSTEAD of x */) {
     using Cfg = FusedSCfg<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
     GeluConsts gk;
     gk.ps = 0.3275911f * 0.70710678f * sinv1;
     gk.cq = 0.84932180f * sinv1;       // sqrt(log2(e) / 2): exp(-v^2 / 2) = exp2(-(cq a)^2)
-    gk.ca = -0.5f * sinv1 * kSplitHiddenScale;
-    gk.cb = sinv1 * kSplitHiddenScale;
+    gk.ca = -0.5f * sinv1 * hscale;
+    gk.cb = sinv1 * hscale;
 
 #define ACX_H8(v_) __builtin_bit_cast(h8, v_)
 #define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
@@ -473,7 +473,7 @@ static int launch_fused_s_cfg(const BlockW& w, const float* y, float* x, long lo
     const long long blocks = (M + Cfg::kPix - 1) / Cfg::kPix;
     mlp_fused_split_kernel<C, LNOUT><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(
         y, x, reinterpret_cast<const char*>(w.wpack_s), w.b1, w.b2, M, 1.0f / (kSplitLnScale * w.w1s_scale),
-        1.0f / (kSplitHiddenScale * w.w2s_scale), reinterpret_cast<char*>(ln_out));
+        1.0f / (w.hid_scale * w.w2s_scale), w.hid_scale, reinterpret_cast<char*>(ln_out));
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

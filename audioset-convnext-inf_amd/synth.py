@@ -106,6 +106,57 @@ def synth_state_dict(seed=0):
     return sd
 
 
+def stress_state_dict(seed=0):
+    """Weights with the statistics of a TRAINED ConvNeXt rather than of a fresh initialisation (no checkpoint ships
+    with the reference and there is no network): the cases a homogeneous Gaussian recipe cannot reach.
+      * LayerNorm weights log-uniform over [1e-2, 30] (block norms and downsample norms), random sign on a tenth
+      * layer scale gamma log-uniform over [1e-5, 1]
+      * per block, 6 "outlier" hidden units: pwconv1 rows x 300..3000 (pre-activations in the thousands, past the
+        4094 where a fixed 2^4 fp16 hidden scale would saturate) with the matching pwconv2 columns scaled down, as
+        trained networks balance them; 3 input columns of pwconv1 x 100
+      * depthwise-conv biases with a common offset in every other block: per-pixel |mean| / std of the tensor
+        entering the LayerNorm around 20 (cancellation in any algebraic LayerNorm)
+      * one downsample conv with weights spanning 6 decades across output channels
+    The residual stream stays O(1..10), so the absolute tolerances of the parity tests keep their meaning."""
+    sd = synth_state_dict(seed)
+    rs = np.random.RandomState(seed + 4242)
+
+    def logu(lo, hi, n):
+        return np.exp(rs.uniform(np.log(lo), np.log(hi), size=n))
+
+    def put(key, arr):
+        sd[key] = torch.from_numpy(np.ascontiguousarray(arr)).to(torch.float32).reshape(sd[key].shape)
+
+    for i in range(1, 4):
+        C = DIMS[i - 1]
+        put("downsample_layers.%d.0.weight" % i, logu(1e-2, 30.0, C) * np.where(rs.rand(C) < 0.1, -1.0, 1.0))
+        w = sd["downsample_layers.%d.1.weight" % i].numpy().astype(np.float64)
+        w /= np.sqrt(56.0)                                  # LN weights above have rms 7.5: keep the conv output O(1)
+        if i == 2:
+            w *= logu(1e-6, 1.0, DIMS[i])[:, None, None, None]
+        put("downsample_layers.%d.1.weight" % i, w)
+    for s in range(4):
+        C = DIMS[s]
+        for j in range(DEPTHS[s]):
+            p = "stages.%d.%d." % (s, j)
+            put(p + "norm.weight", logu(1e-2, 30.0, C) * np.where(rs.rand(C) < 0.1, -1.0, 1.0))
+            put(p + "gamma", logu(1e-5, 1.0, C))
+            w1 = sd[p + "pwconv1.weight"].numpy().astype(np.float64) / 7.5     # typical pre-activation back to O(1)
+            w2 = sd[p + "pwconv2.weight"].numpy().astype(np.float64)
+            rows = rs.choice(4 * C, size=6, replace=False)
+            boost = logu(300.0, 3000.0, 6)
+            w1[rows] *= boost[:, None]
+            w2[:, rows] /= boost[None, :]
+            cols = rs.choice(C, size=3, replace=False)
+            w1[:, cols] *= 100.0
+            put(p + "pwconv1.weight", w1)
+            put(p + "pwconv2.weight", w2)
+            if (s + j) % 2 == 1:
+                b = sd[p + "dwconv.bias"].numpy().astype(np.float64)
+                put(p + "dwconv.bias", b + 20.0 * (1.0 if j % 2 else -1.0))
+    return sd
+
+
 def state_dict_digest(sd):
     """sha256 over key names + raw bytes, to prove two sides hold the same weights."""
     h = hashlib.sha256()

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds diagnostic variants of libacx into build/variants/ (run here; the .so files travel with gpurun).
+set -e
+cd "$(dirname "$0")/../.."
+CS=audioset-convnext-inf_amd/csrc
+mkdir -p build/variants
+build() {   # name, file to recompile, flags
+  local name=$1 file=$2; shift 2
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -fvisibility=hidden -DACX_BUILD "$@" -c $CS/$file.hip -o build/variants/$name.$file.o
+  local objs=""
+  for f in api frontend stem dwconv gemm gemm_bf16 gemm_split mlp_fused mlp_fused_split misc; do
+    if [ "$f" = "$file" ]; then objs="$objs build/variants/$name.$file.o"; else objs="$objs build/acx/$f.o"; fi
+  done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libacx_$name.so $objs
+}
+build syncstage gemm_split -DACX_DBG_SYNC_STAGE &
+build oneterm gemm_split -DACX_DBG_ONE_TERM &
+build lds80 gemm_split -DACX_DBG_LDS80 &
+build lds120 gemm_split -DACX_DBG_LDS120 &
+wait
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -w -shared -fPIC -o build/variants/libfeprobe.so tools/race2/fe_probe.hip
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -w -shared -fPIC -o build/variants/libvalucls.so tools/race2/valu_classes.hip
+ls -la build/variants/*.so
