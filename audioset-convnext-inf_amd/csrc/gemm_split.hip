@@ -84,6 +84,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+#ifdef ACX_DBG_EXCL        // diagnostic: every wave claims the SIMD's whole register file (512 = v255 + a255)
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, v255" ::: "v255", "a255");
+#endif
 #ifdef ACX_SLAB_CLOCK
     unsigned long long ck0 = 0, rt0 = 0;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck0), "=s"(rt0) :: "memory");
@@ -430,7 +433,9 @@ static int launch_s_cfg(const GemmSParams& p0, hipStream_t s) {
     const long long tiles_m = (p.M + kBM - 1) / kBM;
     const long long blocks = tiles_m * p.tiles_n;
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: grid too large");
-#if defined(ACX_DBG_LDS120)      // diagnostic: one workgroup per CU and no room for a 48-KB neighbour
+#if defined(ACX_DBG_EXCL)        // diagnostic: the workgroup claims the CU's whole LDS
+    constexpr size_t lds = 160 * 1024;
+#elif defined(ACX_DBG_LDS120)      // diagnostic: one workgroup per CU and no room for a 48-KB neighbour
     constexpr size_t lds = 120 * 1024;
 #elif defined(ACX_DBG_LDS80)     // diagnostic: two workgroups fill the CU's LDS
     constexpr size_t lds = 80 * 1024;

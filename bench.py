@@ -2,7 +2,12 @@
 """Headline benchmark: clips/sec of the audio-tagging hot path (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--mode logits|scene|frame]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, launcher form)
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself: N fresh
+worker processes are spawned BEFORE this process makes any GPU call (never a re-exec), rank 0 prints the line, and
+the exit code is non-zero unless all N ranks joined the RCCL group (`rccl_ranks` on the line).  `--gpus` that
+disagrees with a launcher's WORLD_SIZE is an error, not a warning.
 
 One "step" = one pass of the hot path (waveform -> logits+probs) over one batch of synthetic 10 s /
 32 kHz clips that is already resident in HBM.  N = 1 runs BASELINE config 2 (ConvNeXt-Tiny, bs=64,
@@ -14,9 +19,13 @@ weight replica) and includes the one collective of the path -- the RCCL all-gath
 in the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline     -- the dominant kernel class (the fp32-MFMA pointwise GEMMs): algorithmic FLOPs per
-                  launch / average launch duration (HIP events on the launch stream, taken in a separate
-                  profiled pass of the same workload so that event overhead stays out of `value`).
+  roofline     -- the dominant KERNEL (by device time; the event classes pw1 + pw2 are one kernel,
+                  gemm_split_kernel, and are merged): algorithmic FLOPs per launch / average launch duration (HIP
+                  events on the launch stream, taken in a separate profiled pass of the same workload so that
+                  event overhead stays out of `value`).  In fp32_split arithmetic every algorithmic fp32 flop is
+                  three fp16 MFMA flops, so `peak` is the dense fp16 matrix peak / 3 (833 TFLOP/s algorithmic);
+                  `frac_executed` (= frac) and `frac_algorithmic_vs_fp16_peak` (algorithmic flops against the
+                  raw 2 500 TFLOP/s) are both given.
   kernels      -- the same for every kernel class, with the HBM roofline for the byte-bound ones.
   cpu_baseline -- the CPU oracle (oracle/ref_cpu.py, torch-CPU fp32, the reference's op sequence) timed
                   on this box's host cores on a bounded sample of the same workload (N = 1, rank 0 only).
@@ -118,19 +127,20 @@ def measured_traffic():
         return {}, None
 
 
-def cpu_baseline(batch=8, reps=3):
-    """Time the oracle on the host cores.  torch-CPU scales badly past a few dozen threads on this graph
-    (and the box may expose more logical CPUs than it grants), so first probe a few thread counts on one
-    clip, then time `batch` 10 s clips per call with the best one: best of `reps` after the warm-up."""
+def cpu_baseline():
+    """Time the oracle on the host cores (B in {1, 8, 64}, best clips/s reported).  torch-CPU scales badly
+    past a few dozen threads on this graph (and the box may expose more logical CPUs than it grants), so first probe
+    a few thread counts on two clips, then time B = 1 (3 reps), 8 (2 reps) and 64 (1 rep) with the best one:
+    about 20-30 s of CPU work in all."""
     from oracle import ref_cpu
     sd = synth.synth_state_dict(0)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    wav = synth.synth_waveforms(batch, CLIP_SAMPLES, seed=1234)
+    wav = synth.synth_waveforms(64, CLIP_SAMPLES, seed=1234)
     probe = {}
-    for n in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
+    for n in sorted({min(avail, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(n)
         ref_cpu.forward(sd, wav[:1])
         t0 = time.perf_counter()
@@ -138,55 +148,129 @@ def cpu_baseline(batch=8, reps=3):
         probe[n] = 2 / (time.perf_counter() - t0)
     threads = max(probe, key=probe.get)
     torch.set_num_threads(threads)
-    best = float("inf")
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        ref_cpu.forward(sd, wav)
-        best = min(best, time.perf_counter() - t0)
-    value = max(batch / best, probe[threads])
+    per_batch = {}
+    for b, reps in ((1, 3), (8, 2), (64, 1)):
+        best = float("inf")
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ref_cpu.forward(sd, wav[:b])
+            best = min(best, time.perf_counter() - t0)
+        per_batch[b] = b / best
+    value = max(per_batch.values())
     return {"value": value, "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": "%d clips x 10 s @ 32 kHz through oracle/ref_cpu.forward (torch-CPU fp32, the reference's op "
-                      "sequence), best of %d; thread-count probe (clips/s on 2 clips): %s; %d logical CPUs available"
-                      % (batch, reps, {k: round(v, 2) for k, v in probe.items()}, avail)}
+            "clips_per_s_by_batch": {str(k): round(v, 3) for k, v in per_batch.items()},
+            "sample": "oracle/ref_cpu.forward (torch-CPU fp32, the reference's op sequence) on 10 s @ 32 kHz clips at "
+                      "batch 1 (best of 3), 8 (best of 2) and 64 (one pass); value = the best of the three; "
+                      "thread-count probe (clips/s on 2 clips): %s; %d logical CPUs available"
+                      % ({k: round(v, 2) for k, v in probe.items()}, avail)}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: spawn N fresh ranks (this parent has made no GPU call and makes
+    none), relay rank 0's JSON line, fail unless every rank exits cleanly."""
+    import subprocess
+    dry = "--dry-run" in argv
+    if not dry:
+        have = torch.cuda.device_count()          # counts devices without initialising the GPU runtime state
+        if have < n:
+            print("bench.py: --gpus %d requested but only %d GPU(s) visible" % (n, have), file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        print("bench.py: rank exit codes %s" % rcs, file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--mode", default="logits", choices=["logits", "scene", "frame"])
-    ap.add_argument("--precision", default="fp32_split", choices=["fp32_split", "fp32", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("ACX_PRECISION", "fp32_split"), choices=["fp32_split", "fp32", "bf16"],
                     help="fp32_split (default) and fp32 both meet BASELINE configs[1]'s 1e-3 fp32 parity: split = fp32 "
                          "operands as fp16 hi+lo pairs on the fp16 matrix cores, fp32 = v_mfma_f32_32x32x2_f32; "
                          "bf16 = the arithmetic of configs[2] (bf16 contractions, fp32 LayerNorm / residual / accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU plumbing check of the multi-rank path (gloo, a stand-in model, no GPU): launch, rendezvous, "
+                         "barriers, gather and the JSON line; the line is marked dry_run and measures nothing")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d disagrees with WORLD_SIZE %d set by the launcher" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     dist = None
+    dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank,
-                                device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if args.dry_run:
+            dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
+        else:
+            dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+    if not args.dry_run:
+        torch.cuda.set_device(dev)
+    sync = (lambda: None) if args.dry_run else (lambda: torch.cuda.synchronize(dev))
+    joined = 1
+    if dist is not None:        # every rank must be in the group before anything is timed
+        t = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        joined = int(t.item())
+        if joined != world:
+            print("bench.py: only %d of %d ranks joined" % (joined, world), file=sys.stderr)
+            sys.exit(3)
 
     from audioset_convnext_inf_amd import parallel
-    model = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
-                          use_speed_perturb=False)
-    model.load_state_dict(synth.synth_state_dict(0))
-    model = model.to(dev).eval().set_precision(args.precision)
     bf16 = args.precision == "bf16"
     split = args.precision == "fp32_split"
     B = args.batch
-    wav = synth.synth_waveforms(B, CLIP_SAMPLES, seed=1234 + rank).to(dev)
+    if args.dry_run:
+        class _StandIn:          # per-row function of the input: exercises sharding / gather, computes nothing real
+            def __call__(self, x):
+                lg = x[:, :527].clone()
+                return {"clipwise_output": torch.sigmoid(lg), "clipwise_logits": lg}
+            def forward_scene_embeddings(self, x):
+                return x[:, :768].clone()
+            def forward_frame_embeddings(self, x):
+                return x[:, :768 * 31 * 7].reshape(-1, 768, 31, 7).clone()
+        model = _StandIn()
+        wav = synth.synth_waveforms(B, CLIP_SAMPLES, seed=1234 + rank)
+    else:
+        model = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
+                              use_speed_perturb=False)
+        model.load_state_dict(synth.synth_state_dict(0))
+        model = model.to(dev).eval().set_precision(args.precision)
+        wav = synth.synth_waveforms(B, CLIP_SAMPLES, seed=1234 + rank).to(dev)
     fn = {"logits": lambda: model(wav)["clipwise_logits"], "scene": lambda: model.forward_scene_embeddings(wav),
           "frame": lambda: model.forward_frame_embeddings(wav)}[args.mode]
 
@@ -198,22 +282,25 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
+        out = step()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if args.mode != "frame" and out.shape[0] != world * B:
+            print("bench.py: gathered %d rows, expected %d" % (out.shape[0], world * B), file=sys.stderr)
+            sys.exit(4)
 
     line = {
         "metric": "clips/sec (10 s @ 32 kHz, ConvNeXt-Tiny, bs=64)", "value": world * B * args.steps / elapsed,
@@ -222,7 +309,7 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16" if bf16 else ("f32 (GEMM operands as fp16 hi+lo pairs = 24 significant bits, 3 fp16 MFMAs per "
                                       "product, fp32 accumulate; all else fp32)" if split else "f32"),
-        "data": "synthetic",
+        "data": "synthetic", "rccl_ranks": joined,
         "config": {"workload": "ConvNeXt-Tiny bs=%d per GPU, synthetic 10 s @ 32 kHz waveforms resident in HBM, "
                                "waveform -> %s, %s" % (B, args.mode, "bf16 contractions with fp32 LayerNorm (arithmetic of "
                                                        "BASELINE configs[2])" if bf16 else
@@ -233,6 +320,15 @@ def main():
                    "parallelism": "clips sharded %d-way, full weight replica per GPU, RCCL all-gather of logits"
                                   % world if world > 1 else "single GPU"},
     }
+    if args.dry_run:
+        line.update({"dry_run": True, "value": None, "ms_per_step": None,
+                     "note": "plumbing check on CPU/gloo with a stand-in model: nothing was measured"})
+        if rank == 0:
+            print(json.dumps(line))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if rank == 0 and not args.no_profile:
         ctx = model.native_context(dev)
@@ -253,45 +349,60 @@ def main():
                           "tflops": flops / (ms * 1e-3) / 1e12 if flops else None,
                           "algorithmic_GBs": nbytes / (ms * 1e-3) / 1e9}
         line["kernels"] = kernels
-        names = {"pw1": "gemm_f32_kernel (LayerNorm+pwconv1+GELU epilogue, stages 2-3)",
-                 "pw2": "gemm_f32_kernel (pwconv2+gamma+residual epilogue, stages 2-3)",
-                 "mlp_fused": "mlp_fused_kernel (LN+pwconv1+GELU+pwconv2+residual, stages 0-1)"}
-        if bf16:
-            names = {"pw1": "gemm_bf16_kernel (pwconv1+GELU epilogue, bf16 hidden out)",
-                     "pw2": "gemm_bf16_kernel (pwconv2+gamma+residual epilogue)",
-                     "mlp_fused": "mlp_fused_bf16_kernel"}
-        if split:
-            names = {"pw1": "gemm_split_kernel (pwconv1+GELU epilogue, S16 hidden out, stages 2-3)",
-                     "pw2": "gemm_split_kernel (pwconv2+gamma+residual epilogue, stages 2-3)",
-                     "mlp_fused": "mlp_fused_split_kernel (LN+pwconv1+GELU+pwconv2+residual, stages 0-1)"}
-        # split mode executes 3 fp16 MFMA flops per algorithmic fp32 flop: price the EXECUTED matrix flops against
-        # the dense fp16 peak (equivalently: algorithmic flops against peak / 3)
-        mfma_peak = MFMA_BF16_PEAK_TF if (bf16 or split) else MFMA_F32_PEAK_TF
+        # the matrix kernels by NAME: the event classes pw1 and pw2 are launches of one kernel
+        gemm_name = {"fp32": "gemm_f32_kernel", "bf16": "gemm_bf16_kernel", "fp32_split": "gemm_split_kernel"}[args.precision]
+        fused_name = {"fp32": "mlp_fused_kernel", "bf16": "mlp_fused_bf16_kernel", "fp32_split": "mlp_fused_split_kernel"}[args.precision]
+        groups = {gemm_name + " (pwconv1+GELU and pwconv2+residual launches, two-GEMM stages)": ("pw1", "pw2"),
+                  fused_name + " (LN+pwconv1+GELU+pwconv2+residual in one launch)": ("mlp_fused",)}
+        merged = {}
+        for name, ks in groups.items():
+            ks = [k for k in ks if k in kernels]
+            if not ks:
+                continue
+            n = sum(kernels[k]["launches_per_step"] for k in ks)
+            merged[name] = {"ms": sum(kernels[k]["ms_per_step"] for k in ks), "launches": n,
+                            "flops": sum(work[k][0] for k in ks), "bytes": sum(work[k][1] for k in ks)}
+        # split mode executes 3 fp16 MFMA flops per algorithmic fp32 flop: the algorithmic peak of that arithmetic is the
+        # dense fp16 peak / 3
+        raw_peak = MFMA_BF16_PEAK_TF if (bf16 or split) else MFMA_F32_PEAK_TF
         mfma_mult = 3.0 if split else 1.0
-        dom = max((k for k in names if k in kernels), key=lambda k: kernels[k]["ms_per_step"])
-        per_launch_flops = work[dom][0] / kernels[dom]["launches_per_step"]
-        avg_launch_s = kernels[dom]["ms_per_step"] * 1e-3 / kernels[dom]["launches_per_step"]
-        ach = mfma_mult * per_launch_flops / avg_launch_s / 1e12
+        peak = raw_peak / mfma_mult
+        dom = max(merged, key=lambda k: merged[k]["ms"])
+        g = merged[dom]
+        per_launch_flops = g["flops"] / g["launches"]
+        avg_launch_s = g["ms"] * 1e-3 / g["launches"]
+        ach = per_launch_flops / avg_launch_s / 1e12
         traffic, traffic_src = measured_traffic()
         tr = lambda k: (traffic.get(k, {}).get("hbm_traffic_bytes_per_launch") if B == 64 else None)
-        line["roofline"] = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": mfma_peak,
-                            "unit": "TFLOP/s", "frac": ach / mfma_peak, "traffic": tr(dom) if not bf16 else None,
-                            "traffic_source": traffic_src, "avg_launch_ms": avg_launch_s * 1e3,
-                            "flops_per_launch": mfma_mult * per_launch_flops,
-                            "algorithmic_fp32_flops_per_launch": per_launch_flops,
-                            "algorithmic_bytes_per_launch": work[dom][1] / kernels[dom]["launches_per_step"]}
+        dom_classes = [k for k in groups[dom] if k in kernels]
+        tr_dom = [tr(k) for k in dom_classes]
+        tr_dom = (sum(t * kernels[k]["launches_per_step"] for t, k in zip(tr_dom, dom_classes)) / g["launches"]
+                  if all(t is not None for t in tr_dom) and not bf16 else None)
+        line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                            "frac": ach / peak, "frac_executed": mfma_mult * ach / raw_peak,
+                            "frac_algorithmic_vs_fp16_peak" if (split or bf16) else "frac_algorithmic": ach / raw_peak,
+                            "peak_note": ("dense fp16 MFMA peak %.0f TFLOP/s / %d MFMAs per fp32 product" % (raw_peak, int(mfma_mult)))
+                                         if split else "dense MFMA peak of the operand type",
+                            "traffic": tr_dom, "traffic_source": traffic_src, "avg_launch_ms": avg_launch_s * 1e3,
+                            "launches_per_step": g["launches"], "ms_per_step": g["ms"],
+                            "algorithmic_flops_per_launch": per_launch_flops,
+                            "executed_mfma_flops_per_launch": mfma_mult * per_launch_flops,
+                            "algorithmic_bytes_per_launch": g["bytes"] / g["launches"]}
         if split:
-            pk = 1024 * 1024 * SPLIT_SHADER_CLOCK_GHZ / 1e3        # SIMDs x flop/cycle/SIMD x GHz -> TFLOP/s
+            pk = 1024 * 1024 * SPLIT_SHADER_CLOCK_GHZ / 1e3 / 3.0     # SIMDs x flop/cycle/SIMD x GHz / 3 -> TFLOP/s algorithmic
             line["roofline"].update({"shader_clock_GHz_measured_in_lab": SPLIT_SHADER_CLOCK_GHZ,
                                      "peak_at_that_clock": pk, "frac_at_that_clock": ach / pk})
         if bf16:        # at bf16 rates the GEMMs are bound by their HBM traffic (the hidden activation), not the matrix pipe
-            gbs = work[dom][1] / kernels[dom]["launches_per_step"] / avg_launch_s / 1e9
-            if gbs / HBM_PEAK_GBS > ach / mfma_peak:
+            gbs = g["bytes"] / g["launches"] / avg_launch_s / 1e9
+            if gbs / HBM_PEAK_GBS > ach / peak:
                 line["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": gbs / HBM_PEAK_GBS, "mfma_tflops": ach})
-        mf = mfma_mult * sum(work[k][0] for k in names) / sum(kernels[k]["ms_per_step"] * 1e-3 for k in names if k in kernels) / 1e12
-        line["roofline_all_pointwise"] = {"bound": "mfma", "achieved": mf, "peak": mfma_peak, "unit": "TFLOP/s",
-                                          "frac": mf / mfma_peak}
+        line["roofline_other_matrix_kernels"] = {
+            k: {"achieved": v["flops"] / (v["ms"] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, "ms_per_step": v["ms"], "launches_per_step": v["launches"]}
+            for k, v in merged.items() if k != dom}
+        mf = sum(v["flops"] for v in merged.values()) / sum(v["ms"] * 1e-3 for v in merged.values()) / 1e12
+        line["roofline_all_pointwise"] = {"bound": "mfma", "achieved": mf, "peak": peak, "unit": "TFLOP/s", "frac": mf / peak}
         dw = kernels["dwconv"]
         line["roofline_dwconv"] = {"kernel": "dwconv7_kernel", "bound": "hbm", "achieved": dw["algorithmic_GBs"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dw["algorithmic_GBs"] / HBM_PEAK_GBS,

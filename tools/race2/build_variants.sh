@@ -17,6 +17,7 @@ build syncstage gemm_split -DACX_DBG_SYNC_STAGE &
 build oneterm gemm_split -DACX_DBG_ONE_TERM &
 build lds80 gemm_split -DACX_DBG_LDS80 &
 build lds120 gemm_split -DACX_DBG_LDS120 &
+build excl gemm_split -DACX_DBG_EXCL &
 wait
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -w -shared -fPIC -o build/variants/libfeprobe.so tools/race2/fe_probe.hip
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -w -shared -fPIC -o build/variants/libvalucls.so tools/race2/valu_classes.hip

@@ -9,7 +9,7 @@ what = sys.argv[1]; burn_blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 102
 vc = ctypes.CDLL(os.path.join(ROOT, "build", "variants", "libvalucls.so"))
 vc.cls_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 vc.burn_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-NAMES = ["v_fma_f32", "v_pk_fma_f32", "v_pk_mul/add_f32", "v_fma_f64", "v_mad_u64_u32/lshl_b64", "v_mul/add_f32", "v_pk_mov_b32+pk", "v_pk_fma_f16"]
+NAMES = ["v_fma_f32", "v_pk_fma_f32", "v_pk_mul/add_f32", "v_fma_f64", "v_mad_u64_u32/lshl_b64", "v_mul/add_f32", "v_pk_mov_b32+pk", "v_pk_fma_f16", "v_pk_mul/add_f32 SGPR-pair src", "v_pk_fma_f32 op_sel/neg VGPR", "v_fma/mul_f32 SGPR src", "v_pk complex product SGPR+modifiers"]
 side = torch.cuda.Stream(); side_sp = ctypes.c_void_p(side.cuda_stream); null_sp = ctypes.c_void_p(0)
 seed = torch.randn(65536, device="cuda"); VB = 4096; ROUNDS = 600
 scratch = torch.zeros(4096, device="cuda")
@@ -38,11 +38,11 @@ def victim(cls, sp):
     o = torch.empty(VB * 256, dtype=torch.int32, device="cuda")
     assert vc.cls_launch(cls, seed.data_ptr(), o.data_ptr(), VB, ROUNDS, sp) == 0
     return o
-refs = [victim(c, null_sp) for c in range(8)]; torch.cuda.synchronize()
-again = [victim(c, null_sp) for c in range(8)]; torch.cuda.synchronize()
+refs = [victim(c, null_sp) for c in range(len(NAMES))]; torch.cuda.synchronize()
+again = [victim(c, null_sp) for c in range(len(NAMES))]; torch.cuda.synchronize()
 assert all(torch.equal(a, b) for a, b in zip(refs, again)), "victims not deterministic on an idle GPU"
 res = []
-for c in range(8):
+for c in range(len(NAMES)):
     bad_runs = bad_thr = 0
     for it in range(6):
         torch.cuda.synchronize()

@@ -4,10 +4,12 @@
 // same inputs must agree bit for bit.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstring>
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int CLS>
-__global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ seed, unsigned* __restrict__ out, int rounds) {
+__global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ seed, unsigned* __restrict__ out, int rounds,
+                                                   unsigned long long sm /* (m, -m) */, unsigned long long sk /* (k, -k) */, float smf, float skf) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     float a = seed[(gid * 4) & 0xffff], b = seed[(gid * 4 + 1) & 0xffff], c = seed[(gid * 4 + 2) & 0xffff], d = seed[(gid * 4 + 3) & 0xffff];
     const float m = 0.999f, k = 1e-3f;
@@ -40,6 +42,24 @@ __global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ seed
         } else if (CLS == 6) {   // v_pk_mov_b32 / v_mov_b64-style 64-bit moves + v_pk_add_f32
             asm volatile("v_pk_mov_b32 %1, %0, %0 op_sel:[1,0]\n\tv_pk_add_f32 %0, %1, %2\n\tv_pk_mov_b32 %1, %0, %0 op_sel:[1,0]\n\tv_pk_mul_f32 %0, %1, %3"
                          : "+v"(x), "+v"(y) : "v"(kk), "v"(mm));
+        } else if (CLS == 8) {   // v_pk_mul_f32 / v_pk_add_f32 with SGPR-pair operands, no modifiers
+            asm volatile("v_pk_mul_f32 %0, %0, %2\n\tv_pk_add_f32 %0, %0, %3\n\tv_pk_mul_f32 %1, %1, %2\n\tv_pk_add_f32 %1, %1, %0"
+                         : "+v"(x), "+v"(y) : "s"(sm), "s"(sk));
+        } else if (CLS == 9) {   // v_pk_fma_f32, VGPR operands, op_sel / neg modifiers as the compiler uses them for complex products
+            asm volatile("v_pk_mul_f32 %1, %0, %2 op_sel_hi:[1,0]\n\t"
+                         "v_pk_fma_f32 %0, %0, %3, %1 op_sel:[0,0,1] op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+                         "v_pk_fma_f32 %1, %0, %3, %1 op_sel:[0,0,1] op_sel_hi:[1,0,0]\n\t"
+                         "v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]"
+                         : "+v"(x), "+v"(y) : "v"(mm), "v"(kk));
+        } else if (CLS == 10) {  // v_fma_f32 / v_mul_f32 with 32-bit SGPR operands
+            asm volatile("v_fma_f32 %0, %0, %2, %1\n\tv_mul_f32 %1, %3, %1\n\tv_fma_f32 %1, %0, %3, %1\n\tv_mul_f32 %0, %2, %0"
+                         : "+v"(a), "+v"(b) : "s"(smf), "s"(skf));
+        } else if (CLS == 11) {  // the compiled complex product: SGPR-pair operands AND modifiers
+            asm volatile("v_pk_mul_f32 %1, %0, %2 op_sel_hi:[1,0]\n\t"
+                         "v_pk_fma_f32 %0, %0, %3, %1 op_sel:[0,0,1] op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+                         "v_pk_fma_f32 %1, %0, %3, %1 op_sel:[0,0,1] op_sel_hi:[1,0,0]\n\t"
+                         "v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]"
+                         : "+v"(x), "+v"(y) : "s"(sm), "s"(sk));
         } else if (CLS == 7) {   // packed fp16: v_pk_fma_f16
             unsigned p = __float_as_uint(a), q = __float_as_uint(b);
             asm volatile("v_pk_fma_f16 %0, %0, %2, %3\n\tv_pk_fma_f16 %1, %1, %2, %0\n\tv_pk_fma_f16 %0, %1, %2, %3\n\tv_pk_fma_f16 %1, %0, %2, %1"
@@ -55,15 +75,24 @@ __global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ seed
 
 extern "C" int cls_launch(int cls, const float* seed, unsigned* out, int blocks, int rounds, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    const float m = 0.999f, k = 1e-3f, nm = -m, nk = -k;
+    unsigned um, unm, uk, unk;
+    memcpy(&um, &m, 4); memcpy(&unm, &nm, 4); memcpy(&uk, &k, 4); memcpy(&unk, &nk, 4);
+    const unsigned long long sm = um | ((unsigned long long)unm << 32), sk = uk | ((unsigned long long)unk << 32);
+#define ARGS seed, out, rounds, sm, sk, m, k
     switch (cls) {
-        case 0: cls_kernel<0><<<blocks, 256, 0, s>>>(seed, out, rounds); break;
-        case 1: cls_kernel<1><<<blocks, 256, 0, s>>>(seed, out, rounds); break;
-        case 2: cls_kernel<2><<<blocks, 256, 0, s>>>(seed, out, rounds); break;
-        case 3: cls_kernel<3><<<blocks, 256, 0, s>>>(seed, out, rounds); break;
-        case 4: cls_kernel<4><<<blocks, 256, 0, s>>>(seed, out, rounds); break;
-        case 5: cls_kernel<5><<<blocks, 256, 0, s>>>(seed, out, rounds); break;
-        case 6: cls_kernel<6><<<blocks, 256, 0, s>>>(seed, out, rounds); break;
-        case 7: cls_kernel<7><<<blocks, 256, 0, s>>>(seed, out, rounds); break;
+        case 0: cls_kernel<0><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 1: cls_kernel<1><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 2: cls_kernel<2><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 3: cls_kernel<3><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 4: cls_kernel<4><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 5: cls_kernel<5><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 6: cls_kernel<6><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 7: cls_kernel<7><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 8: cls_kernel<8><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 9: cls_kernel<9><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 10: cls_kernel<10><<<blocks, 256, 0, s>>>(ARGS); break;
+        case 11: cls_kernel<11><<<blocks, 256, 0, s>>>(ARGS); break;
         default: return -1;
     }
     return (int)hipGetLastError();
@@ -94,7 +123,29 @@ __global__ __launch_bounds__(256) void burn(float* out, int iters) {
     for (int n = 0; n < NACC; ++n) for (int i = 0; i < 16; ++i) s += c[n][i];
     if (s == 123.456f) out[threadIdx.x] = s;
 }
+// live operands: 8 + 8 distinct random fragment sets, 4 independent accumulators: successive MFMAs never see the same
+// operand registers (as in a GEMM main loop), still no memory or LDS instruction in the loop
+__global__ __launch_bounds__(256) void burn_live(float* out, int iters) {
+    h8 a[8], b[8];
+    for (int s = 0; s < 8; ++s)
+        for (int i = 0; i < 8; ++i) {
+            const unsigned h = hashu(threadIdx.x * 128 + s * 8 + i + blockIdx.x * 7919);
+            a[s][i] = (_Float16)(((int)(h & 0xffff) - 32768) * (1.0f / 32768.f));
+            b[s][i] = (_Float16)(((int)(h >> 16) - 32768) * (1.0f / 32768.f));
+        }
+    f16v c[4];
+    for (int n = 0; n < 4; ++n) for (int i = 0; i < 16; ++i) c[n][i] = 0.f;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(u + 3 * n) & 7], b[(5 * u + n) & 7], c[n], 0, 0, 0);
+    float s = 0.f;
+    for (int n = 0; n < 4; ++n) for (int i = 0; i < 16; ++i) s += c[n][i];
+    if (s == 123.456f) out[threadIdx.x] = s;
+}
 extern "C" int burn_launch(int nacc, float* out, int blocks, int iters, void* stream) {
+    if (nacc == 8) { burn_live<<<blocks, 256, 0, (hipStream_t)stream>>>(out, iters); return (int)hipGetLastError(); }
     hipStream_t s = (hipStream_t)stream;
     if (nacc == 1) burn<1><<<blocks, 256, 0, s>>>(out, iters);
     else if (nacc == 4) burn<4><<<blocks, 256, 0, s>>>(out, iters);
