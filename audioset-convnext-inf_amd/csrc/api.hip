@@ -533,6 +533,8 @@ int acx_create(int hip_device, acx_ctx** out) {
     {
         const char* e = std::getenv("ACX_SPLIT_STREAMS");
         c->split_streams = !(e && e[0] == '0');
+        const char* e2 = std::getenv("ACX_SPLIT_TWO_STREAMS");
+        c->split_two_streams = e2 && e2[0] == '1';
     }
     *out = c;
     return ACX_OK;
@@ -658,7 +660,7 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
     // Not in fp32_split arithmetic: a split GEMM running next to an FFT-type kernel of ANOTHER stream (our own log-mel
     // kernel, rocFFT) perturbs that kernel's results on this platform -- reproduced, not yet explained
     // (tools/canary/, DESIGN.md "Open issue") -- so that arithmetic keeps to one stream.
-    if (c->split_streams && c->precision != ACX_PREC_F32_SPLIT && !c->prof.on && B >= kSplitMinBatch) {
+    if (c->split_streams && (c->precision != ACX_PREC_F32_SPLIT || c->split_two_streams) && !c->prof.on && B >= kSplitMinBatch) {
         const int B0 = (B + 1) / 2, B1 = B / 2;
         Plan p0, p1;
         ACX_TRY(make_plan(B0, L, &p0));

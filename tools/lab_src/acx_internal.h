@@ -2,7 +2,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -41,32 +40,6 @@ void set_error(const char* fmt, ...);
         int rc_ = (expr);         \
         if (rc_ != ACX_OK) return rc_; \
     } while (0)
-
-// hipFuncSetAttribute acts on the CURRENT device: remember, per kernel, which devices already have the attribute
-// (one process may drive several GPUs; launches may come from several threads)
-struct DeviceOnce {
-    std::atomic<unsigned long long> mask{0};
-};
-template <typename K>
-inline int set_max_dynamic_lds(DeviceOnce& once, K kernel, size_t bytes) {
-    int dev = 0;
-    ACX_HIP(hipGetDevice(&dev));
-    const unsigned long long bit = 1ULL << (dev & 63);
-    if (once.mask.load(std::memory_order_acquire) & bit) return ACX_OK;
-    ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    once.mask.fetch_or(bit, std::memory_order_release);
-    return ACX_OK;
-}
-
-// CU-exclusive workgroups: a workgroup that holds ALL of a CU's LDS (kCuLdsBytes requested at launch)
-// and all of its vector registers (512 threads x 256 or 256 threads x 512 registers) cannot share the CU with any other
-// wave -- the hardware's own resource accounting enforces it.  Every kernel that runs dense 16-bit MFMA on live data
-// is launched this way: next to such a kernel, packed-FP32 VALU instructions (v_pk_*_f32) of a co-resident foreign
-// wave return wrong results on this platform (tools/race2/).
-constexpr size_t kCuLdsBytes = 160 * 1024;
-// forces the register allocation of the calling kernel up to `v<n>` (asm clobber of the highest register wanted)
-#define ACX_CLAIM_VGPR(n) asm volatile("" ::: "v" #n)
-#define ACX_CLAIM_AGPR(n) asm volatile("" ::: "a" #n)
 
 struct HostTensor {
     std::vector<float> data;
@@ -142,7 +115,6 @@ struct acx_ctx {
     // two-way batch split over two HIP streams (fork/join by events): kernels of the two halves co-run, so
     // an HBM-bound kernel of one half fills the matrix-pipe-bound phases of the other and vice versa
     bool split_streams = true;    // ACX_SPLIT_STREAMS=0 turns it off
-    bool split_two_streams = false;   // fp32_split arithmetic: two-stream batch split only with ACX_SPLIT_TWO_STREAMS=1
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     acx::Profile prof;

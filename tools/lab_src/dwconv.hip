@@ -18,7 +18,12 @@ constexpr int kDwSlice = 32;      // channels per workgroup (staged as 8 x float
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifdef ACX_LAB_DW_STAMP      // diagnostic build (tools/dw_lab.hip): where does a tile spend its cycles?
+__device__ unsigned long long acx_dw_stamps[8];
+#define ACX_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
 #define ACX_STAMP(var)
+#endif
 
 // Streaming form: a workgroup owns (32-channel slice, column strip of TW pixels, segment of row tiles of the
 // stacked batch) and walks DOWN the images.  An LDS ring of TH+6 input rows is kept; each step computes TH output rows from
@@ -177,11 +182,18 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
     const int rd_off = (strip * Cfg::WT) * 16 + l16;   // float2 offset of this thread's first input column
     float* const yb = y + (long long)(w0 + strip * Cfg::WT) * C + c0 + 2 * l16;
 
+#ifdef ACX_LAB_DW_STAMP
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, acc_s[5] = {0, 0, 0, 0, 0};
+#endif
     f32x2 so0[Cfg::WT], so1[Cfg::WT];
 #pragma unroll
     for (int i = 0; i < Cfg::WT; ++i) so0[i] = so1[i] = bv;
     float *yp0 = nullptr, *yp1 = nullptr;              // where so0[] / so1[] belong (null: nothing pending)
+#ifdef ACX_LAB_DW_NOSTORE
+#define ACX_DW_FLUSH1(yp_, so_) if (yp_ != nullptr && so_[0][0] == 12345.678f) { _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x2*>(yp_ + (long long)i * C) = so_[i]; }
+#else
 #define ACX_DW_FLUSH1(yp_, so_) if (yp_ != nullptr) { _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x2*>(yp_ + (long long)i * C) = so_[i]; }
+#endif
 #define ACX_DW_FLUSH ACX_DW_FLUSH1(yp0, so0) ACX_DW_FLUSH1(yp1, so1)
     for (int t = t_begin; t < t_end; ++t) {
         const int h0 = t * TH;
@@ -192,9 +204,11 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
         const int nf_n = (int)__umulhi((unsigned)next_first, magic);
         const int nf_r = next_first - nf_n * Hp;
         const bool edge = nf_r + TH > H || nf_n >= B;
+#ifndef ACX_LAB_DW_NOLOAD
         if (more) {
             if (edge) { ACX_DW_LOAD_EDGE(next_first) } else { ACX_DW_LOAD_FAST(nf_n * H + nf_r) }
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // Outputs leave one tile LATE, from their own register set, right BEHIND the next prefetch: hipcc puts a
         // vmcnt(0) in front of the prefetch address set-up (it cannot prove the staging registers idle across
@@ -278,8 +292,10 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
         }
         ACX_DW_READ_W(wA, 0)
         ACX_DW_READ_I0(0)
+#ifndef ACX_LAB_DW_NOFMA
         ACX_DW_IROW(0, wA, wC, wB) ACX_DW_IROW(1, wB, wA, wC) ACX_DW_IROW(2, wC, wB, wA) ACX_DW_IROW(3, wA, wC, wB)
         ACX_DW_IROW(4, wB, wA, wC) ACX_DW_IROW(5, wC, wB, wA) ACX_DW_IROW(6, wA, wC, wB) ACX_DW_IROW(7, wB, wA, wC)
+#endif
 #undef ACX_DW_ROWP
 #undef ACX_DW_READ_W
 #undef ACX_DW_READ_I0
@@ -300,6 +316,9 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
             ACX_STAMP(ts4)
             __syncthreads();
             ACX_STAMP(ts5)
+#ifdef ACX_LAB_DW_STAMP
+            acc_s[0] += ts1 - ts0; acc_s[1] += ts2 - ts1; acc_s[2] += ts3 - ts2; acc_s[3] += ts4 - ts3; acc_s[4] += ts5 - ts4;
+#endif
         }
 #pragma unroll
         for (int i = 0; i < Cfg::WT; ++i) { so0[i] = a0[i]; so1[i] = a1[i]; }
@@ -313,6 +332,12 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
     ACX_DW_FLUSH
 #undef ACX_DW_FLUSH
 #undef ACX_DW_FLUSH1
+#ifdef ACX_LAB_DW_STAMP
+    if ((tid & 63) == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&acx_dw_stamps[i], acc_s[i]);
+        atomicAdd(&acx_dw_stamps[5], (unsigned long long)(t_end - t_begin - 1));
+    }
+#endif
 #undef ACX_DW_LOAD_FAST
 #undef ACX_DW_VROW
 #undef ACX_DW_LOAD_EDGE
@@ -459,16 +484,22 @@ static int launch_dw_cfg(const BlockW& w, int C, const float* x, float* y, int B
         return ACX_OK;
     }
     using Cfg = DwCfg<TW, TH>;
-    static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &dwconv7_kernel<TW, TH>, Cfg::kLdsBytes));
+    static bool attr_set = false;
+    if (!attr_set) {
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_kernel<TW, TH>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::kLdsBytes));
+        attr_set = true;
+    }
     const int Hv = B * (H + 3) - 3;                    // stacked rows (no gap after the last clip)
     const int tiles_w = W / TW, tiles_h = (Hv + TH - 1) / TH;
     const long long columns = (long long)tiles_w * (C / kDwSlice);
     // Workgroups = (column strips x channel slices) x row segments of the stacked image.  Two workgroups are
     // resident per CU (512 slots): ONE round of equal segments -- every further round pays the ring prologue
     // and the store drain again, and a fractional round idles the chip for a whole workgroup life.
-    constexpr int kTargetWorkgroups = 512;      // one round: 2 workgroups per CU
-    int n_seg = (int)(kTargetWorkgroups / columns);
+#ifndef ACX_LAB_DW_WGS
+#define ACX_LAB_DW_WGS 512   // diagnostic override (tools/dw_lab.hip): target number of workgroups
+#endif
+    int n_seg = (int)(ACX_LAB_DW_WGS / columns);
     if (n_seg > tiles_h / 2) n_seg = tiles_h / 2;
     if (n_seg < 1) n_seg = 1;
     const long long blocks = columns * n_seg;

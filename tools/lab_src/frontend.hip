@@ -14,6 +14,13 @@ namespace acx {
 
 constexpr int kFrontWaves = 4;
 
+#ifdef ACX_FE_DEBUG      // diagnostic build (tools/race_fe_debug.py): per-frame checksums of the pipeline stages
+__device__ float acx_fe_dbg[65536 * 4];
+__device__ __forceinline__ float wave_sum_dbg(float v) {
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+#endif
 
 constexpr int kMelLds = 1024;        // banded mel weights kept in LDS when they fit (librosa's 224-bin bank: 884)
 
@@ -87,6 +94,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                 v[r] = cf_make(a * hw[r].x, c * hw[r].y);
             }
         }
+#ifdef ACX_FE_DEBUG
+        {
+            float c = 0.f;
+            for (int r = 0; r < 8; ++r) c += v[r].x + 3.f * v[r].y;
+            c = wave_sum_dbg(c);
+            if (lane == 0 && valid && f < 65536) acx_fe_dbg[4 * f + 0] = c;
+        }
+#endif
         // pass Ns=1 straight from registers, then two LDS-exchange passes
         cf* bufA = lds.buf[wave][0];
         cf* bufB = lds.buf[wave][1];
@@ -103,6 +118,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = bufB[fft_pad(lane + 64 * r)];
         dst = fft512_pass(v, lane, 64, lds.tw);
+#ifdef ACX_FE_DEBUG
+        {
+            float c = 0.f;
+            for (int r = 0; r < 8; ++r) c += fabsf(v[r].x) + fabsf(v[r].y);
+            c = wave_sum_dbg(c);
+            if (lane == 0 && valid && f < 65536) acx_fe_dbg[4 * f + 1] = c;      // after the last butterfly (two LDS exchanges done)
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 8; ++r) bufA[fft_pad(dst + r * 64)] = v[r];
         __syncthreads();
@@ -119,6 +142,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
             P[512] = X.x * X.x + X.y * X.y;
         }
         __syncthreads();
+#ifdef ACX_FE_DEBUG
+        {
+            float c = 0.f;
+            for (int r = 0; r < 8; ++r) c += P[lane + 64 * r];
+            c = wave_sum_dbg(c);
+            if (lane == 0 && valid && f < 65536) acx_fe_dbg[4 * f + 2] = c;      // power spectrum (third exchange done)
+        }
+#endif
         // banded mel filter + dB + bn0
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -139,6 +170,11 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
     }
 }
 
+#ifdef ACX_FE_DEBUG
+extern "C" __attribute__((visibility("default"))) int acx_debug_fe_read(float* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(acx_fe_dbg), (size_t)n * 4);
+}
+#endif
 
 int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s) {
     static float* d_one = nullptr;   // identity affine when bn0 is not applied (tests)

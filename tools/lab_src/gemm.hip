@@ -24,7 +24,12 @@ namespace acx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef ACX_LAB_GEMM_STAMP    // diagnostic build (tools/gemm_lab.hip): cycle shares of a k-tile
+__device__ unsigned long long acx_gemm_stamps[8];
+#define ACX_GSTAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
 #define ACX_GSTAMP(var)
+#endif
 
 constexpr int kBK = 32;
 constexpr int kRowBytes = kBK * 4;        // 128-B LDS rows
@@ -252,6 +257,10 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
         ACX_READ_FRAGS(af0, bf0, ab, bb, 0)
         ACX_READ_FRAGS(af1, bf1, ab, bb, 1)
     }
+#ifdef ACX_LAB_GEMM_STAMP
+    unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, gs[4] = {0, 0, 0, 0}, gk0 = 0, gk1 = 0;
+    ACX_GSTAMP(gk0)
+#endif
     for (int kt = 0; kt + 1 < nk; ++kt) {
         ACX_GSTAMP(g0)
         const char* ab = As + (kt & 1) * A_TILE + a_frag_off;
@@ -267,12 +276,20 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
         char* adn = a_dst + ((kt + 1) & 1) * A_TILE;
         char* bdn = b_dst + ((kt + 1) & 1) * B_TILE;
         __builtin_amdgcn_sched_barrier(0);
+#ifndef ACX_LAB_NO_GLOBAL
         ACX_MFMA_GROUP_DMA(af0, bf0, a_src, A_DMA, koff1, adn)
+#else
+        ACX_MFMA_GROUP(af0, bf0)
+#endif
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af1, bf1)       // see ACX_TOUCH: drain the OLD reads before issuing new ones
         ACX_READ_FRAGS(af0, bf0, ab, bb, 2)
         __builtin_amdgcn_sched_barrier(0);
+#ifndef ACX_LAB_NO_GLOBAL
         ACX_MFMA_GROUP_DMA(af1, bf1, b_src, B_DMA, (long long)k1, bdn)
+#else
+        ACX_MFMA_GROUP(af1, bf1)
+#endif
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af0, bf0)
         ACX_READ_FRAGS(af1, bf1, ab, bb, 3)
@@ -290,7 +307,13 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
         ACX_TOUCH(af0, bf0)
         ACX_READ_FRAGS(af1, bf1, abn, bbn, 1)
         ACX_GSTAMP(g3)
+#ifdef ACX_LAB_GEMM_STAMP
+        gs[0] += g1 - g0; gs[1] += g2 - g1; gs[2] += g3 - g2;
+#endif
     }
+#ifdef ACX_LAB_GEMM_STAMP
+    ACX_GSTAMP(gk1)
+#endif
     {
         const char* ab = As + ((nk - 1) & 1) * A_TILE + a_frag_off;
         const char* bb = Bs + ((nk - 1) & 1) * B_TILE + b_frag_off;
@@ -312,6 +335,19 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
 #undef ACX_TOUCH
 
     // ---- epilogue: D tile layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) -----
+#ifdef ACX_LAB_GEMM_STAMP
+    unsigned long long ge0 = 0;
+    ACX_GSTAMP(ge0)
+#endif
+#ifdef ACX_LAB_NO_EPI      // diagnostic (tools/gemm_lab.hip): main loop only
+    {
+        float t = 0.f;
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) p.out[tid] = t;
+        return;
+    }
+#endif
     const bool full = m0 + kBM <= p.M;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -357,24 +393,47 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
             }
         }
     }
+#ifdef ACX_LAB_GEMM_STAMP
+    {
+        unsigned long long ge1 = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ACX_GSTAMP(ge1)
+        if (lane == 0) {
+            atomicAdd(&acx_gemm_stamps[0], gs[0]); atomicAdd(&acx_gemm_stamps[1], gs[1]); atomicAdd(&acx_gemm_stamps[2], gs[2]);
+            atomicAdd(&acx_gemm_stamps[3], gk1 - gk0); atomicAdd(&acx_gemm_stamps[4], ge1 - ge0);
+            atomicAdd(&acx_gemm_stamps[5], (unsigned long long)(nk - 1)); atomicAdd(&acx_gemm_stamps[6], 1ULL);
+            atomicAdd(&acx_gemm_stamps[7], ge0 - gk1);
+        }
+    }
+#endif
 }
 
+#ifndef ACX_LAB_EXTRA_LDS
+#define ACX_LAB_EXTRA_LDS 0
+#endif
 template <int BM, int BN>
-constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * kRowBytes; }
+constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * kRowBytes + ACX_LAB_EXTRA_LDS; }
 
-// DW = 1 builds the variant with a 5th, dedicated LDS-DMA wave.  Measured NEGATIVE on MI355X (tools/
+// ACX_GEMM_DW=1 builds the variant with a 5th, dedicated LDS-DMA wave.  Measured NEGATIVE on MI355X (tools/
 // gemm_lab: s2.pw1 657 vs 581 us, s2.pw2 742 vs 627 us): one wave cannot issue the 32 pieces of a tile and see
 // them land within one k-tile of MFMA time, so it becomes the critical path; 8 pieces on each MFMA wave is faster.
+#ifndef ACX_GEMM_DW
+#define ACX_GEMM_DW 0
+#endif
 template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
 static int launch_cfg(const GemmParams& p0, hipStream_t s) {
-    constexpr int DW = 0;
+    constexpr int DW = ACX_GEMM_DW;
     GemmParams p = p0;
     p.tiles_n = p.N / BN;
     const long long tiles_m = (p.M + kBM - 1) / kBM;
     const long long blocks = tiles_m * p.tiles_n;
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm: grid too large");
-    static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER, DW>, gemm_lds_bytes<kBM, BN>()));
+    static bool attr_set = false;
+    if (!attr_set) {
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER, DW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<kBM, BN>()));
+        attr_set = true;
+    }
     gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER, DW><<<dim3((unsigned)blocks), dim3(256 + 64 * DW), gemm_lds_bytes<kBM, BN>(), s>>>(p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;

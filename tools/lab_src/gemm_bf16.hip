@@ -236,8 +236,12 @@ static int launch_bf_cfg(const GemmBfParams& p0, hipStream_t s) {
     const long long blocks = tiles_m * p.tiles_n;
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm_bf16: grid too large");
     constexpr size_t lds = (size_t)2 * (kBM + BN) * kBfRowBytes;
-    static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER>, lds));
+    static bool attr_set = false;
+    if (!attr_set) {
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
     gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;

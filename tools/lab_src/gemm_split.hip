@@ -16,11 +16,8 @@
 // GELU epilogue (hidden activation scaled by 2^4, clamped to the fp16 range) and acx_finalize for the weights
 // (scaled per layer to max |w| in [2^14, 2^15)).  The epilogue multiplies the accumulator by the exact inverse.
 //
-// Tiling / staging as gemm.hip, but one 8-wave workgroup per CU: 256 x BN x 32 per workgroup (4 x 2 waves, each 64 x BN/2),
-// both operands by LDS-DMA with the XOR swizzle on the source address, fragments double-buffered in registers.
-// The workgroup is CU-EXCLUSIVE (acx_internal.h, kCuLdsBytes): it claims all 160 KB of LDS and 512 x 256 registers, so no
-// foreign wave can be co-resident with its MFMA loop (packed-FP32 VALU work of a co-resident wave goes wrong next to
-// it on this platform -- tools/race2/).  A k-tile is only 2 x TM*TN*3 MFMAs of 32 cycles, so
+// Tiling / staging as gemm.hip: 128 x BN x 32 per workgroup, both operands by LDS-DMA with the XOR swizzle on the
+// source address, fragments double-buffered in registers.  A k-tile is only 2 x TM*TN*3 MFMAs of 32 cycles, so
 // the pipeline is one k-tile deeper than the fp32 kernel's: tile t+2 is in flight while tile t is multiplied.
 #include "acx_internal.h"
 #include "split_math.h"
@@ -31,6 +28,9 @@ namespace acx {
 constexpr int kSRowBytes = 128;     // 32 k per LDS row
 constexpr int kSBK = 32;
 
+#ifdef ACX_SLAB_CLOCK       // diagnostic build (tools/split_lab.hip): in-kernel shader clock = d s_memtime / d s_memrealtime
+__device__ unsigned long long acx_gs_clock[4];
+#endif
 
 struct GemmSParams {
     const char* A; const char* Wt; const float* bias; void* out; const float* resid;
@@ -42,6 +42,23 @@ struct GemmSParams {
 };
 
 __device__ __forceinline__ void lds_dma16_s(const char* gsrc, char* lds_wave_base) {
+#ifdef ACX_SLAB_NO_DMA      // diagnostic: no operand traffic at all (LDS holds garbage)
+    return;
+#endif
+#ifdef ACX_DBG_SYNC_STAGE   // diagnostic: register staging (global_load -> ds_write_b128) instead of LDS-DMA, same layout
+    {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(gsrc);
+        *reinterpret_cast<f32x4*>(lds_wave_base + 16 * (threadIdx.x & 63)) = v;
+        return;
+    }
+#endif
+#ifdef ACX_DBG_PLAIN_LOADS  // diagnostic: the same bytes by ordinary 16-B loads into registers (LDS keeps garbage)
+    {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(gsrc + 16 * (threadIdx.x & 63) * 0);
+        asm volatile("" :: "v"(v));
+        return;
+    }
+#endif
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
@@ -67,10 +84,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    // claim the whole register budget of two waves per SIMD (with 512 threads hipcc keeps everything, accumulators
-    // included, in v0..v255; tools/check_exclusive.py verifies the emitted descriptor)
-    static_assert(NW == 8, "CU-exclusive launch: 8 waves x 256 registers");
-    ACX_CLAIM_VGPR(255);
+#ifdef ACX_DBG_EXCL        // diagnostic: every wave claims the SIMD's whole register file (512 = v255 + a255)
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, v255" ::: "v255", "a255");
+#endif
+#ifdef ACX_SLAB_CLOCK
+    unsigned long long ck0 = 0, rt0 = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck0), "=s"(rt0) :: "memory");
+#endif
     long long lid = blockIdx.x;
     {   // XCD-contiguous tile order (see gemm.hip)
         const long long nwg = gridDim.x, per = (nwg + 7) >> 3, full = nwg - (per - 1) * 8;
@@ -97,7 +117,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
             const long long b = t / p.Ho;
             a_src[i] = p.A + (((b * p.H + 2 * ho) * p.W + 2 * wo) * p.C) * 4 + 16 * chunk;
         } else {
+#ifdef ACX_SLAB_A_RESIDENT     // diagnostic: the A stream comes from L2 (256 distinct rows), not from HBM
+            a_src[i] = p.A + (m & 255) * p.K * 4 + 16 * chunk;
+#else
             a_src[i] = p.A + m * p.K * 4 + 16 * chunk;
+#endif
         }
     }
     const char* b_src[B_DMA];
@@ -134,6 +158,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
     }
     const int a_frag_off = wm * TM * 32 * kSRowBytes;
     const int b_frag_off = wn * TN * 32 * kSRowBytes;
+#ifdef ACX_DBG_NO_LDSREAD
+#define ACX_READ_FRAGS(F, abase, bbase, s) { _Pragma("unroll") for (int i = 0; i < TM; ++i) { asm volatile("" : "+v"(F##ah[i])); asm volatile("" : "+v"(F##al[i])); } _Pragma("unroll") for (int j = 0; j < TN; ++j) { asm volatile("" : "+v"(F##bh[j])); asm volatile("" : "+v"(F##bl[j])); } }
+#else
 #define ACX_READ_FRAGS(F, abase, bbase, s)                                                              \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
@@ -145,7 +172,41 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
             F##bl[j] = *reinterpret_cast<const f32x4*>((bbase) + j * 32 * kSRowBytes + foff_lo[s]);    \
         }                                                                                              \
     }
+#endif
 #define ACX_H8(x) __builtin_bit_cast(h8, x)
+#ifdef ACX_SLAB_NO_MFMA
+#define ACX_MFMA1(term, i, j, F) asm volatile("" :: "v"(F##ah[i]), "v"(F##bl[j]), "v"(F##al[i]), "v"(F##bh[j]));
+#elif defined(ACX_DBG_BF16_MFMA)     /* diagnostic: same kernel, bf16 opcode (numerically meaningless) */
+typedef __bf16 dbg_b8 __attribute__((ext_vector_type(8)));
+#define ACX_MFMA1(term, i, j, F)                                                                       \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbg_b8, (term) == 0 ? F##bl[j] : F##bh[j]),  \
+                                                            __builtin_bit_cast(dbg_b8, (term) == 1 ? F##al[i] : F##ah[i]), acc[i][j], 0, 0, 0);
+#elif defined(ACX_DBG_TWO_TERM)
+#define ACX_MFMA1(term, i, j, F)                                                                       \
+    if ((term) >= 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bh[j]), ACX_H8((term) == 1 ? F##al[i] : F##ah[i]), acc[i][j], 0, 0, 0); \
+    else asm volatile("" :: "v"(F##bl[j]));
+#elif defined(ACX_DBG_NOP_TERM)
+#define ACX_MFMA1(term, i, j, F)                                                                       \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8((term) == 0 ? F##bl[j] : F##bh[j]),     \
+                                                       ACX_H8((term) == 1 ? F##al[i] : F##ah[i]), acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_nop(7);
+#elif defined(ACX_DBG_SHAPE16)      /* diagnostic: the same loop with 16x16x32 MFMAs, two per 32x32x16 (same flops, same
+                                       operands and LDS reads; numerically meaningless) -- what would the other shape buy? */
+typedef float dbg_f4 __attribute__((ext_vector_type(4)));
+#define ACX_MFMA1(term, i, j, F)                                                                       \
+    {                                                                                                  \
+        dbg_f4 lo_ = __builtin_shufflevector(acc[i][j], acc[i][j], 0, 1, 2, 3);                        \
+        dbg_f4 hi_ = __builtin_shufflevector(acc[i][j], acc[i][j], 4, 5, 6, 7);                        \
+        lo_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ACX_H8((term) == 0 ? F##bl[j] : F##bh[j]), ACX_H8((term) == 1 ? F##al[i] : F##ah[i]), lo_, 0, 0, 0); \
+        hi_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ACX_H8((term) == 1 ? F##al[i] : F##ah[i]), ACX_H8((term) == 0 ? F##bl[j] : F##bh[j]), hi_, 0, 0, 0); \
+        acc[i][j][0] = lo_[0]; acc[i][j][1] = lo_[1]; acc[i][j][2] = lo_[2]; acc[i][j][3] = lo_[3];    \
+        acc[i][j][4] = hi_[0]; acc[i][j][5] = hi_[1]; acc[i][j][6] = hi_[2]; acc[i][j][7] = hi_[3];    \
+    }
+#elif defined(ACX_DBG_ONE_TERM)
+#define ACX_MFMA1(term, i, j, F)                                                                       \
+    if ((term) == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(F##bh[j]), ACX_H8(F##ah[i]), acc[i][j], 0, 0, 0); \
+    else asm volatile("" :: "v"(F##bl[j]), "v"(F##al[i]));
+#else
 #define ACX_MFMA1(term, i, j, F)     /* term 0: lo x hi, 1: hi x lo, 2: hi x hi */                      \
     if (SWAP) {                                                                                        \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8((term) == 0 ? F##bl[j] : F##bh[j]),  \
@@ -154,9 +215,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8((term) == 0 ? F##al[i] : F##ah[i]),  \
                                                            ACX_H8((term) == 1 ? F##bl[j] : F##bh[j]), acc[i][j], 0, 0, 0); \
     }
+#endif
     // term-major order: MFMAs on the same accumulator are TM*TN instructions apart
+#ifdef ACX_SLAB_SETPRIO
+#define ACX_PRIO_HI __builtin_amdgcn_s_setprio(3);
+#define ACX_PRIO_LO __builtin_amdgcn_s_setprio(0);
+#else
 #define ACX_PRIO_HI
 #define ACX_PRIO_LO
+#endif
 #define ACX_MFMA_STEP(F)                                                                               \
     {                                                                                                  \
         ACX_PRIO_HI                                                                                    \
@@ -194,7 +261,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         _Pragma("unroll") for (int j = 0; j < TN; ++j) { asm volatile("" :: "v"(F##bh[j])); asm volatile("" :: "v"(F##bl[j])); } \
     }
 
+#ifdef ACX_SLAB_NO_BARRIER     // diagnostic: k-loop without its barrier (wrong results)
+#define ACX_LOOP_BARRIER
+#else
 #define ACX_LOOP_BARRIER __syncthreads();
+#endif
     const int nk = p.K / kSBK;
     // prologue: tiles 0 and 1 in flight, fragments of tile 0 in registers
     ACX_DMA_TILE(a_koff(0), 0LL, 0)
@@ -224,7 +295,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         ACX_LOOP_BARRIER
         ACX_READ_FRAGS(F0, abn, bbn, 0)
         __builtin_amdgcn_sched_barrier(0);
+#ifdef ACX_GS_ONE_IN_FLIGHT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifdef ACX_GS_BURST
+        ACX_DMA_TILE(ka, (long long)k2 * 4, kt & 1)
+        ACX_MFMA_STEP(F1)
+#else
         ACX_MFMA_STEP_DMA(F1, ka, (long long)k2 * 4, kt & 1)
+#endif
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(F0)
         ACX_READ_FRAGS(F1, abn, bbn, 1)
@@ -254,6 +333,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
 #undef ACX_TOUCH
 #undef ACX_H8
 
+#ifdef ACX_SLAB_CLOCK
+    {
+        unsigned long long ck1 = 0, rt1 = 0;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck1), "=s"(rt1) :: "memory");
+        if (tid == 0) { atomicAdd(&acx_gs_clock[0], ck1 - ck0); atomicAdd(&acx_gs_clock[1], rt1 - rt0); atomicAdd(&acx_gs_clock[2], 1ULL); }
+    }
+#endif
+#ifdef ACX_SLAB_NO_EPI      // diagnostic (tools/split_lab.hip): main loop only
+    {
+        float t = 0.f;
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) reinterpret_cast<float*>(p.out)[tid] = t;
+        return;
+    }
+#endif
     const float sinv = p.sinv;
     if (EPI == 1) {
         GeluConsts gk;          // GELU of v = a * sinv, result x p.hscale (see split_math.h)
@@ -338,10 +433,21 @@ static int launch_s_cfg(const GemmSParams& p0, hipStream_t s) {
     const long long tiles_m = (p.M + kBM - 1) / kBM;
     const long long blocks = tiles_m * p.tiles_n;
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: grid too large");
-    static_assert((size_t)2 * (kBM + BN) * kSRowBytes <= kCuLdsBytes, "tile does not fit the LDS");
-    constexpr size_t lds = kCuLdsBytes;          // all of it: CU-exclusive (see the header comment)
-    static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER>, lds));
+#if defined(ACX_DBG_EXCL)        // diagnostic: the workgroup claims the CU's whole LDS
+    constexpr size_t lds = 160 * 1024;
+#elif defined(ACX_DBG_LDS120)      // diagnostic: one workgroup per CU and no room for a 48-KB neighbour
+    constexpr size_t lds = 120 * 1024;
+#elif defined(ACX_DBG_LDS80)     // diagnostic: two workgroups fill the CU's LDS
+    constexpr size_t lds = 80 * 1024;
+#else
+    constexpr size_t lds = (size_t)2 * (kBM + BN) * kSRowBytes;
+#endif
+    static bool attr_set = false;
+    if (!attr_set) {
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
     gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(64 * WM * WN), lds, s>>>(p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
@@ -349,11 +455,29 @@ static int launch_s_cfg(const GemmSParams& p0, hipStream_t s) {
 
 template <int EPI, int GATHER>
 static int launch_s_bn(const GemmSParams& p, hipStream_t s) {
-    // every N of the model (192, 384, 768, 1536, 3072) is a multiple of 192: 256 x 192 tiles -- 36 MFMAs per barrier and
-    // the fewest operand bytes per flop through the LDS-DMA path; 256 x 128 for other multiples of 128
-    if (p.N % 192 == 0) return launch_s_cfg<256, 192, 4, 2, EPI, GATHER>(p, s);
-    if (p.N % 128 == 0) return launch_s_cfg<256, 128, 4, 2, EPI, GATHER>(p, s);
-    ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: N=%d is not a multiple of 192 or 128", p.N);
+    const long long tiles128 = ((p.M + 127) / 128) * (p.N % 128 == 0 ? p.N / 128 : p.N / 96);
+    const bool small = tiles128 < 800;
+#ifdef ACX_SPLIT_BIG
+    if (p.N % 256 == 0 && p.K >= 384) return launch_s_cfg<256, 256, 2, 2, EPI, GATHER>(p, s);
+    if (p.N % 128 == 0 && p.K >= 384) return launch_s_cfg<256, 128, 2, 2, EPI, GATHER>(p, s);
+#endif
+#ifdef ACX_SPLIT_SMALL
+    if (p.N % 128 == 0) return launch_s_cfg<64, 128, 2, 2, EPI, GATHER>(p, s);
+#endif
+#ifdef ACX_SPLIT_8W
+    if (p.N % 128 == 0 && p.K >= 192) return launch_s_cfg<256, 128, 4, 2, EPI, GATHER>(p, s);
+#endif
+    // pwconv1 (N = 4C >= 1536 here): 128 x 192 tiles -- 15 % fewer operand bytes per flop through the LDS-DMA path
+    // and 36 instead of 24 MFMAs per barrier (tools/split_lab: s2.pw1 264 vs 277 us, s3.pw1 200 vs 211)
+#ifndef ACX_SPLIT_NO_W192
+    if (EPI == 1 && p.N % 192 == 0 && p.N >= 768 && !small) return launch_s_cfg<128, 192, 2, 2, EPI, GATHER>(p, s);
+#endif
+    if (p.N % 128 == 0) {
+        if (small) return launch_s_cfg<64, 128, 2, 2, EPI, GATHER>(p, s);
+        return launch_s_cfg<128, 128, 2, 2, EPI, GATHER>(p, s);
+    }
+    if (p.N % 96 == 0) return launch_s_cfg<128, 96, 4, 1, EPI, GATHER>(p, s);
+    ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: N=%d is not a multiple of 96 or 128", p.N);
 }
 
 int launch_gemm_split(acx_ctx* c, const GemmSplitArgs& a, hipStream_t s) {

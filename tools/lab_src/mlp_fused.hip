@@ -219,8 +219,12 @@ __global__ __launch_bounds__(FusedCfg<C>::kThreads) void mlp_fused_kernel(
 template <int C>
 static int launch_fused_cfg(const BlockW& w, const float* y, float* x, long long M, hipStream_t s) {
     using Cfg = FusedCfg<C>;
-    static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_kernel<C>, Cfg::kLdsBytes));
+    static bool attr_set = false;
+    if (!attr_set) {
+        ACX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::kLdsBytes));
+        attr_set = true;
+    }
     const long long blocks = (M + Cfg::kPix - 1) / Cfg::kPix;
     mlp_fused_kernel<C><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(y, x, w.wpack, w.b1, w.b2, M);
     ACX_HIP(hipGetLastError());

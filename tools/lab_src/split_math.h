@@ -36,6 +36,10 @@ __device__ __forceinline__ void gelu_piece2(f32x2 a, f32x2 av, f32x2 t, f32x2 e,
     g = fma2(av * bc2(k.ca), q, pos);
 }
 __device__ __forceinline__ void gelu_piece3(f32x2 g, unsigned& hi, unsigned& lo) {
+#ifdef ACX_FSLAB_NO_GELU    // diagnostic (tools/mlp_split_lab.hip): (almost) no VALU work between the two products
+    hi = __builtin_bit_cast(unsigned, g.x); lo = __builtin_bit_cast(unsigned, g.y);
+    return;
+#endif
     g.x = __builtin_fminf(g.x, 65504.f); g.y = __builtin_fminf(g.y, 65504.f);
     const h2 h = __builtin_convertvector(g, h2);
     const f32x2 back = __builtin_convertvector(h, f32x2);

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Builds diagnostic variants of libacx into build/variants/ (run here; the .so files travel with gpurun).
+# Builds diagnostic variants of libacx (kernel sources WITH the lab switches: tools/lab_src/) into build/variants/ (run here; the .so files travel with gpurun).
 set -e
 cd "$(dirname "$0")/../.."
 CS=audioset-convnext-inf_amd/csrc
 mkdir -p build/variants
 build() {   # name, file to recompile, flags
   local name=$1 file=$2; shift 2
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -fvisibility=hidden -DACX_BUILD "$@" -c $CS/$file.hip -o build/variants/$name.$file.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -fvisibility=hidden -DACX_BUILD "$@" -c tools/lab_src/$file.hip -o build/variants/$name.$file.o
   local objs=""
   for f in api frontend stem dwconv gemm gemm_bf16 gemm_split mlp_fused mlp_fused_split misc; do
     if [ "$f" = "$file" ]; then objs="$objs build/variants/$name.$file.o"; else objs="$objs build/acx/$f.o"; fi
