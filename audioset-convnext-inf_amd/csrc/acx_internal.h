@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -137,14 +138,19 @@ struct acx_ctx {
     float* d_head_w = nullptr;    // [527][768]
     float* d_head_b = nullptr;    // [527]
 
-    int precision = ACX_PREC_F32; // acx_set_precision: ACX_PREC_BF16 runs the dense contractions on bf16 MFMA
+    int precision = ACX_PREC_F32_SPLIT;   // acx_set_precision (include/acx.h): the default equals the Python host's
     bool use_fused_mlp = true;    // ACX_DISABLE_FUSED_MLP=1 turns the fused stage-0/1 MLP kernel off
     // two-way batch split over two HIP streams (fork/join by events): kernels of the two halves co-run, so
     // an HBM-bound kernel of one half fills the matrix-pipe-bound phases of the other and vice versa
     bool split_streams = true;    // ACX_SPLIT_STREAMS=0 turns it off
     bool split_two_streams = false;   // fp32_split arithmetic: two-stream batch split only with ACX_SPLIT_TWO_STREAMS=1
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // fork/join resources per CALLER stream: forwards issued on different streams (or threads) never share an event
+    struct Aux { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    std::map<hipStream_t, Aux> aux;
+    std::mutex aux_mutex;
+    // identity affine for acx_logmel_bn0(apply_bn0 = 0) (tests): per context, i.e. per device
+    float* d_bn_one = nullptr;
+    float* d_bn_zero = nullptr;
     acx::Profile prof;
 };
 

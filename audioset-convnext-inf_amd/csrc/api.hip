@@ -234,6 +234,8 @@ static int finalize_impl(acx_ctx* c) {
         }
         ACX_TRY(upload(c, sc, &c->d_bn_scale));
         ACX_TRY(upload(c, sh, &c->d_bn_shift));
+        ACX_TRY(upload(c, std::vector<float>(kMels, 1.f), &c->d_bn_one));
+        ACX_TRY(upload(c, std::vector<float>(kMels, 0.f), &c->d_bn_zero));
     }
     // ---- stem -------------------------------------------------------------------------------
     ACX_TRY(upload(c, W(c, "downsample_layers.0.0.weight"), &c->d_stem_w));
@@ -527,9 +529,6 @@ int acx_create(int hip_device, acx_ctx** out) {
     acx_ctx* c = new acx_ctx();
     c->device = hip_device;
     ACX_HIP(hipSetDevice(hip_device));
-    ACX_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    ACX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    ACX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     {
         const char* e = std::getenv("ACX_SPLIT_STREAMS");
         c->split_streams = !(e && e[0] == '0');
@@ -546,9 +545,11 @@ void acx_destroy(acx_ctx* c) {
     free_device(c);
     for (auto& r : c->prof.recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    for (auto& kv : c->aux) {
+        if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
+        if (kv.second.join) (void)hipEventDestroy(kv.second.join);
+        if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+    }
     delete c;
 }
 
@@ -617,6 +618,21 @@ int acx_workspace_bytes(const acx_ctx* c, int B, int64_t L, int mode, size_t* ou
     return ACX_OK;
 }
 
+// side stream + fork/join events of the two-stream batch split, one set per caller stream (created on first use)
+static int get_aux(acx_ctx* c, hipStream_t st, acx_ctx::Aux* out) {
+    std::lock_guard<std::mutex> lock(c->aux_mutex);
+    auto it = c->aux.find(st);
+    if (it == c->aux.end()) {
+        acx_ctx::Aux a;
+        ACX_HIP(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+        ACX_HIP(hipEventCreateWithFlags(&a.fork, hipEventDisableTiming));
+        ACX_HIP(hipEventCreateWithFlags(&a.join, hipEventDisableTiming));
+        it = c->aux.emplace(st, a).first;
+    }
+    *out = it->second;
+    return ACX_OK;
+}
+
 static int forward_one(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float* out0, float* out1, char* ws,
                        const Plan& p, hipStream_t st) {
     float* feat = (float*)(ws + p.off_feat);
@@ -657,23 +673,24 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
     // Clips are independent: a large batch runs as two halves on two streams (fork/join with events, so the call
     // still looks like one unit of work on `stream` and stays graph-capturable).  Per-kernel event profiling
     // runs un-split to keep launch durations clean.
-    // Not in fp32_split arithmetic: a split GEMM running next to an FFT-type kernel of ANOTHER stream (our own log-mel
-    // kernel, rocFFT) perturbs that kernel's results on this platform -- reproduced, not yet explained
-    // (tools/canary/, DESIGN.md "Open issue") -- so that arithmetic keeps to one stream.
-    if (c->split_streams && (c->precision != ACX_PREC_F32_SPLIT || c->split_two_streams) && !c->prof.on && B >= kSplitMinBatch) {
+    // The 16-bit-MFMA arithmetics (fp32_split, bf16) run CU-exclusive kernels: nothing co-runs with them on a CU, so the
+    // split buys them nothing (measured +0.7 %) and they keep to one stream unless ACX_SPLIT_TWO_STREAMS=1 asks for it.
+    if (c->split_streams && (c->precision == ACX_PREC_F32 || c->split_two_streams) && !c->prof.on && B >= kSplitMinBatch) {
         const int B0 = (B + 1) / 2, B1 = B / 2;
         Plan p0, p1;
         ACX_TRY(make_plan(B0, L, &p0));
         ACX_TRY(make_plan(B1, L, &p1));
         const size_t per_clip0 = mode == ACX_MODE_FRAME ? (size_t)kDims[3] * p0.Hs[3] * p0.Ws[3]
                                                         : (mode == ACX_MODE_SCENE ? (size_t)kDims[3] : (size_t)kClasses);
-        ACX_HIP(hipEventRecord(c->ev_fork, st));
-        ACX_HIP(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        acx_ctx::Aux aux;
+        ACX_TRY(get_aux(c, st, &aux));
+        ACX_HIP(hipEventRecord(aux.fork, st));
+        ACX_HIP(hipStreamWaitEvent(aux.stream, aux.fork, 0));
         ACX_TRY(forward_one(c, wav, B0, L, mode, out0, out1, ws, p0, st));
         ACX_TRY(forward_one(c, wav + (size_t)B0 * L, B1, L, mode, out0 + B0 * per_clip0, out1 ? out1 + B0 * per_clip0 : nullptr,
-                            ws + p0.total, p1, c->aux_stream));
-        ACX_HIP(hipEventRecord(c->ev_join, c->aux_stream));
-        ACX_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+                            ws + p0.total, p1, aux.stream));
+        ACX_HIP(hipEventRecord(aux.join, aux.stream));
+        ACX_HIP(hipStreamWaitEvent(st, aux.join, 0));
         return ACX_OK;
     }
     Plan p;
@@ -700,32 +717,6 @@ int acx_dwconv7(acx_ctx* c, int stage, int block, const float* x, float* y, floa
     if (!x || !y || B <= 0 || H <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_dwconv7: bad argument");
     if (Wd != (kStemW >> stage)) ACX_FAIL(ACX_ERR_SHAPE, "stage %d has width %d, got %d", stage, kStemW >> stage, Wd);
     return launch_dwconv(c, c->blocks[stage][block], kDims[stage], x, y, stats, B, H, Wd, (hipStream_t)stream);
-}
-
-int acx_block_mlp(acx_ctx* c, int stage, int block, const float* y, const float* stats, float* x, float* hidden, int B,
-                  int H, int Wd, void* stream) {
-    ACX_TRY(need_ready(c));
-    ACX_TRY(check_stage(stage, block));
-    if (!y || !stats || !x || !hidden || B <= 0 || H <= 0 || Wd <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_block_mlp: bad argument");
-    const int C = kDims[stage];
-    const BlockW& bw = c->blocks[stage][block];
-    const int64_t M = (int64_t)B * H * Wd;
-    if (c->precision == ACX_PREC_BF16) return run_mlp_bf16(c, bw, C, y, x, hidden, M, (hipStream_t)stream);
-    if (c->precision == ACX_PREC_F32_SPLIT) {
-        // stages 0-1 run the fused kernel (y is read only); the two-GEMM stages normalise y IN PLACE into S16 form,
-        // which this entry point's const y cannot offer: acx_block is the per-block entry point there
-        if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused_split(c, bw, C, y, x, M, (hipStream_t)stream);
-        ACX_FAIL(ACX_ERR_UNSUPPORTED, "acx_block_mlp: in fp32_split precision stage %d normalises y in place; call acx_block", stage);
-    }
-    if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused(c, bw, C, y, x, M, (hipStream_t)stream);
-    GemmArgs g1{};
-    g1.A = y; g1.Wt = bw.w1; g1.bias = bw.b1; g1.out = hidden; g1.stats = stats; g1.colsum = bw.w1sum; g1.M = M; g1.N = 4 * C; g1.K = C;
-    g1.epi = EPI_GELU; g1.cls = ACX_K_PW1;
-    ACX_TRY(launch_gemm(c, g1, (hipStream_t)stream));
-    GemmArgs g2{};
-    g2.A = hidden; g2.Wt = bw.w2; g2.bias = bw.b2; g2.out = x; g2.resid = x; g2.M = M; g2.N = C; g2.K = 4 * C;
-    g2.epi = EPI_RESID; g2.cls = ACX_K_PW2;
-    return launch_gemm(c, g2, (hipStream_t)stream);
 }
 
 int acx_block_scratch_bytes(int stage, int B, int H, int Wd, size_t* out_bytes) {

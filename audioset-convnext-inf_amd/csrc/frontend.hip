@@ -141,23 +141,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 
 
 int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s) {
-    static float* d_one = nullptr;   // identity affine when bn0 is not applied (tests)
-    static float* d_zero = nullptr;
-    if (!bn && !d_one) {
-        std::vector<float> one(kMels, 1.f), zero(kMels, 0.f);
-        ACX_HIP(hipMalloc(&d_one, kMels * 4));
-        ACX_HIP(hipMalloc(&d_zero, kMels * 4));
-        ACX_HIP(hipMemcpy(d_one, one.data(), kMels * 4, hipMemcpyHostToDevice));
-        ACX_HIP(hipMemcpy(d_zero, zero.data(), kMels * 4, hipMemcpyHostToDevice));
-    }
     long long nframes = (long long)B * T;
     long long blocks = (nframes + kFrontWaves - 1) / kFrontWaves;
     if (blocks > 4096) blocks = 4096;
     ProfScope ps(c, ACX_K_FRONTEND, s);
     logmel_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(wav, L, T, nframes, c->d_hann, c->d_twiddle,
                                                                 c->d_mel_start, c->d_mel_len, c->d_mel_off,
-                                                                c->d_mel_w, c->mel_w_len, bn ? c->d_bn_scale : d_one,
-                                                                bn ? c->d_bn_shift : d_zero, out);
+                                                                c->d_mel_w, c->mel_w_len, bn ? c->d_bn_scale : c->d_bn_one,
+                                                                bn ? c->d_bn_shift : c->d_bn_zero, out);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

@@ -133,7 +133,10 @@ class ConvNeXt(nn.Module):
         self.precision = os.environ.get("ACX_PRECISION", "fp32_split")
         if self.precision not in _ffi.PRECISIONS:
             raise ValueError("ACX_PRECISION must be one of %s" % sorted(_ffi.PRECISIONS))
-        self._ws = {}           # device index -> workspace tensor
+        self._ws = {}           # (device index, stream handle) -> workspace tensor: concurrent forwards on different
+        #                         streams never share scratch memory (the reference module is re-entrant in eval)
+        self._ws_retired = []   # outgrown workspaces stay alive: a captured hipGraph may still point into them
+        self._weights_epoch = 0  # bumped by load_state_dict / _apply / refresh(): forces a repack of the native weights
 
     def _init_weights(self, m):
         if isinstance(m, (nn.Conv2d, nn.Linear)):
@@ -142,7 +145,49 @@ class ConvNeXt(nn.Module):
 
     # ------------------------------------------------------------------------------ native side
     def _signature(self):
-        return (self.precision,) + tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        return (self.precision, self._weights_epoch) + tuple((t.data_ptr(), t._version)
+                                                             for t in self.state_dict(keep_vars=True).values())
+
+    def refresh(self):
+        """Call after editing weights in a way autograd's version counters cannot see (`param.data.mul_(...)`, writes
+        through numpy views): the native contexts repack the weights at the next forward.  `load_state_dict`, `.to()`,
+        `.half()`-style `_apply` calls and ordinary in-place tensor ops are detected without it."""
+        self._weights_epoch += 1
+        return self
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._weights_epoch += 1
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._weights_epoch += 1
+        # contexts and workspaces of devices the module has left are released
+        dev = self.head_audioset.weight.device
+        keep = dev.index if dev.type == "cuda" and dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else None)
+        for idx in [i for i in self._ctx if i != keep]:
+            self._ctx.pop(idx)[0].close()
+        for key in [k for k in self._ws if k[0] != keep]:
+            self._ws.pop(key)
+        if keep is None:
+            self._ws_retired.clear()
+        return out
+
+    def __getstate__(self):
+        # native handles (ctypes) and scratch tensors are per-process state, rebuilt on demand
+        state = self.__dict__.copy()
+        state["_ctx"], state["_ws"], state["_ws_retired"] = {}, {}, []
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k in ("_ctx", "_ws") else ([] if k == "_ws_retired" else copy.deepcopy(v, memo))
+        return new
 
     def set_precision(self, precision):
         """"fp32_split" (default): fp32 GEMM operands carried as fp16 hi + fp16 lo, three fp16 MFMAs per product, fp32
@@ -170,12 +215,13 @@ class ConvNeXt(nn.Module):
 
     def _workspace(self, device, nbytes):
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        ws = self._ws.get(idx)
+        key = (idx, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
-            ws = None
-            self._ws.pop(idx, None)
+            if ws is not None:
+                self._ws_retired.append(ws)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._ws[idx] = ws
+            self._ws[key] = ws
         return ws
 
     def _run(self, x, mode):

@@ -87,12 +87,9 @@ def prepare_clip(waveform, sample_rate, target_rate=32000, target_seconds=10):
     import torch
     import torch.nn.functional as F
     if sample_rate != target_rate:
-        # linear-phase polyphase resampling (scipy) stands in for torchaudio.functional.resample
-        from scipy.signal import resample_poly
-        from math import gcd
-        g = gcd(int(sample_rate), int(target_rate))
-        y = resample_poly(waveform.cpu().numpy(), target_rate // g, sample_rate // g, axis=-1)
-        waveform = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
+        # torchaudio.functional.resample semantics (windowed sinc, width 6, rolloff 0.99): utils/resample.py
+        from .resample import resample
+        waveform = resample(waveform.to(torch.float32), int(sample_rate), int(target_rate))
     n = target_rate * target_seconds
     if waveform.shape[-1] < n:
         waveform = F.pad(waveform, (0, n - waveform.shape[-1]), mode="constant", value=0.0)

@@ -60,9 +60,11 @@ enum acx_mode {
 enum acx_precision {
     ACX_PREC_F32 = 0,         /* v_mfma_f32_32x32x2_f32: fp32 operands on the matrix cores */
     ACX_PREC_BF16 = 1,        /* bf16 operands, fp32 accumulate (NOT within the 1e-3 bar) */
-    ACX_PREC_F32_SPLIT = 2    /* fp32 operands carried as fp16 hi + fp16 lo (24 significant bits), three fp16
+    ACX_PREC_F32_SPLIT = 2    /* DEFAULT.  fp32 operands carried as fp16 hi + fp16 lo (24 significant bits), three fp16
                                * MFMAs per product, fp32 accumulate: fp32-grade results (same parity tests and
-                               * tolerances as ACX_PREC_F32) at 16/3 of the f32-MFMA rate */
+                               * tolerances as ACX_PREC_F32, plus tests/test_gpu_stress.py) at 16/3 of the f32-MFMA
+                               * rate.  Its kernels launch CU-exclusive workgroups (whole LDS + whole register file of
+                               * a CU): work of other streams or processes never shares a CU with them. */
 };
 
 /* kernel classes for acx_profile_read() */
@@ -100,9 +102,10 @@ ACX_API int acx_set_weight(acx_ctx* ctx, const char* state_dict_key, const float
  * May be called again after weights change. */
 ACX_API int acx_finalize(acx_ctx* ctx);
 
-/* Selects enum acx_precision for every later call (default ACX_PREC_F32; the reference has no such switch --
- * its torch equivalent is `model.to(torch.bfloat16)` / autocast around the Linear layers).  Changing it drops
- * the finalized state: call acx_finalize again. */
+/* Selects enum acx_precision for every later call.  Default: ACX_PREC_F32_SPLIT -- the same default as the Python host
+ * (pytorch/convnext.py, ACX_PRECISION overrides it there), so a C caller and a Python caller get the same arithmetic.
+ * The reference has no such switch (its torch equivalent is `model.to(torch.bfloat16)` / autocast around the Linear
+ * layers).  Changing it drops the finalized state: call acx_finalize again. */
 ACX_API int acx_set_precision(acx_ctx* ctx, int precision);
 
 /* Geometry helpers: frames T = L/320+1 (torchlibrosa STFT, hop 320, center) and the spatial size
@@ -132,14 +135,11 @@ ACX_API int acx_stem_ln(acx_ctx* ctx, const float* in, int B, int T, float* out,
  * LayerNorm statistics (mean, rstd) of the output (convnext.py:78) into stats (B*H*W, 2). */
 ACX_API int acx_dwconv7(acx_ctx* ctx, int stage, int block, const float* x, float* y, float* stats, int B,
                 int H, int W, void* stream);
-/* K4: LayerNorm + pwconv1 + GELU + pwconv2 + gamma + residual (convnext.py:78-86).
- * y, stats from acx_dwconv7; x updated in place; hidden = scratch (B*H*W, 4C) fp32.
- * Stages 0-1 (C = 96, 192) run as ONE fused kernel that keeps the hidden activation in registers and
- * computes the LayerNorm statistics itself (stats / hidden are then unused); stages 2-3 run as two
- * MFMA GEMMs.  Set ACX_DISABLE_FUSED_MLP=1 before acx_finalize to force the two-GEMM form everywhere. */
-ACX_API int acx_block_mlp(acx_ctx* ctx, int stage, int block, const float* y, const float* stats, float* x,
-                  float* hidden, int B, int H, int W, void* stream);
-/* whole Block.forward (convnext.py:74-87) on NHWC x, in place. scratch >= acx_block_scratch_bytes */
+/* K3 + K4: whole Block.forward (convnext.py:74-87) on NHWC x, in place: depthwise conv, then LayerNorm + pwconv1 + GELU +
+ * pwconv2 + gamma + residual (convnext.py:78-86).  Stages 0-1 (C = 96, 192) run the MLP as ONE fused kernel that keeps
+ * the hidden activation in registers; stages 2-3 run two MFMA GEMMs through the hidden scratch.  Set
+ * ACX_DISABLE_FUSED_MLP=1 before acx_finalize to force the two-GEMM form everywhere (fp32 precision only).
+ * scratch >= acx_block_scratch_bytes, 256-byte aligned. */
 ACX_API int acx_block(acx_ctx* ctx, int stage, int block, float* x, int B, int H, int W, void* scratch,
               size_t scratch_bytes, void* stream);
 ACX_API int acx_block_scratch_bytes(int stage, int B, int H, int W, size_t* out_bytes);

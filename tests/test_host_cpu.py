@@ -120,3 +120,42 @@ def test_checkpoint_round_trips(tmp_path, synth_sd):
     b = load_checkpoint(convnext_tiny(after_stem_dim=[252, 56]), pth)
     for k, v in synth_sd.items():
         assert torch.equal(a.state_dict()[k], v) and torch.equal(b.state_dict()[k], v)
+
+
+def test_converter_script_writes_a_loadable_safetensors(tmp_path, synth_sd):
+    """convert_pytorch_ckpt_to_safetensors.py (reference :1-21): .pth -> from_pretrained -> model.safetensors, which
+    from_pretrained reads back to the same 190 tensors."""
+    import subprocess
+    import sys
+    pth = str(tmp_path / "ckpt.pth")
+    torch.save({"model": synth_sd}, pth)
+    out = str(tmp_path / "model.safetensors")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "convert_pytorch_ckpt_to_safetensors.py"), "--ckpt", pth, "--out", out],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "# params: 28222767" in r.stdout
+    from audioset_convnext_inf_amd.pytorch.convnext import ConvNeXt
+    m = ConvNeXt.from_pretrained(out)
+    sd = m.state_dict()
+    assert len(sd) == 190
+    for k, v in synth_sd.items():
+        assert torch.equal(sd[k], v), k
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus 2` without a launcher spawns two ranks itself (before any GPU call), they rendezvous
+    (gloo in the dry run), gather, and rank 0 prints the one JSON line with rccl_ranks == 2; a --gpus that disagrees
+    with the launcher's WORLD_SIZE is an error."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "3", "--dry-run"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dry_run"] is True and line["value"] is None
+    assert line["config"]["global_batch"] == 6
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                       text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode == 2 and "disagrees" in r.stderr

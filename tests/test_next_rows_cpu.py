@@ -92,3 +92,64 @@ def test_evaluator_statistics_match_sklearn():
 
 def test_bucket_by_length():
     assert bucket_by_length([10, 20, 10, 30, 20]) == {10: [0, 2], 20: [1, 4], 30: [3]}
+
+
+def test_resample_matches_the_interpolation_formula():
+    """utils/resample.py restates torchaudio.functional.resample (demo_convnext.py:53-59).  Check it against a direct
+    float64 evaluation of the same band-limited interpolation, y[n] = sum_m x[m] h(n / new - m / orig), with
+    h(t) = scale * sinc(base t) * cos^2(pi base t / (2 * 6)) on |base t| <= 6, and against an analytic tone."""
+    import math
+    from audioset_convnext_inf_amd.utils.resample import resample
+    rs = np.random.RandomState(3)
+    for orig, new in ((44100, 32000), (16000, 32000), (48000, 32000), (8000, 32000)):
+        x = rs.standard_normal(3000)
+        y = resample(torch.from_numpy(x.astype(np.float32))[None], orig, new)[0].numpy()
+        assert y.shape[0] == math.ceil(3000 * new / orig)
+        g = math.gcd(orig, new)
+        of, nf = orig // g, new // g
+        base = min(of, nf) * 0.99
+        m = np.arange(3000)
+        for n in rs.randint(0, y.shape[0], size=40):
+            t = (n / nf - m / of) * base
+            h = np.where(np.abs(t) < 6, np.sinc(t) * np.cos(np.clip(t, -6, 6) * math.pi / 12) ** 2, 0.0) * (base / of)
+            assert abs(float(np.dot(x, h)) - y[n]) < 2e-5 * max(1.0, np.abs(x).max())
+    tone = np.sin(2 * np.pi * 1000 * np.arange(22050) / 44100)
+    y = resample(torch.from_numpy(tone.astype(np.float32))[None], 44100, 32000)[0].numpy()
+    ref = np.sin(2 * np.pi * 1000 * np.arange(y.shape[0]) / 32000)
+    assert np.abs(y - ref)[300:-300].max() < 5e-4
+    same = torch.randn(1, 100)
+    assert resample(same, 32000, 32000) is same
+    clip = ut.prepare_clip(torch.from_numpy(tone.astype(np.float32))[None], 44100)          # demo path: resample, then pad
+    assert clip.shape == (1, 320000) and float(clip[0, 16100:].abs().max()) == 0.0
+
+
+def test_hdf5_shard_reader_with_a_stand_in_h5py(tmp_path, monkeypatch):
+    """`ClipShard.from_hdf5` reads the reference's packed format (dataset.py:193-199: audio_name S20, waveform int16
+    (N, L), target bool (N, 527), attr sample_rate).  h5py is not in this image: a stand-in module with the slice of
+    its API that the reader uses (File as a context manager, dataset[:]) executes the code path."""
+    import sys
+    import types
+    rs = np.random.RandomState(1)
+    store = {"waveform": rs.randint(-3000, 3000, size=(5, 640)).astype(np.int16),
+             "target": rs.uniform(size=(5, 527)) < 0.2,
+             "audio_name": np.array([("Y%04d.wav" % i).encode() for i in range(5)], dtype="S20")}
+
+    class _File(dict):
+        def __init__(self, path, mode="r"):
+            assert mode == "r" and path.endswith("eval.h5")
+            super().__init__(store)
+            self.attrs = {"sample_rate": 32000}
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=_File))
+    shard = ClipShard.from_hdf5(str(tmp_path / "eval.h5"))
+    assert len(shard) == 5 and shard.audio_names.tolist() == ["Y%04d.wav" % i for i in range(5)]
+    batches = list(evaluate_batches(shard, batch_size=2))
+    assert [b["waveform"].shape[0] for b in batches] == [2, 2, 1]
+    np.testing.assert_array_equal(batches[0]["waveform"], (store["waveform"][:2] / 32767.0).astype(np.float32))
+    assert batches[2]["target"].dtype == np.float32 and batches[2]["audio_name"][0] == "Y0004.wav"
