@@ -88,6 +88,7 @@ struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layou
     uint16_t* w1s = nullptr; // split mode: folded pwconv1 in S16 form (gemm_split.hip), scaled by w1s_scale
     uint16_t* w2s = nullptr; // split mode: gamma * pwconv2 in S16 form, scaled by w2s_scale
     uint16_t* wpack_s = nullptr; // split mode, C = 96/192: chunk-major [W1c | W2c] S16 image (mlp_fused_split.hip)
+    uint16_t* wstream_s = nullptr; // split mode, C = 384: segment stream in consumption order, LDS image order (mlp_fused_wide.hip)
     float w1s_scale = 1.f, w2s_scale = 1.f;
     float hid_scale = 1.f;   // split mode: power-of-two scale of the S16 hidden activation (GELU output)
 };
@@ -214,6 +215,10 @@ int launch_mlp_fused(acx_ctx* c, const BlockW& w, int C, const float* y, float* 
 // ln_out != nullptr: do not write x; write LayerNorm(x_new) as S16 rows (the downsample GEMM's operand) there instead
 int launch_mlp_fused_split(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
                            void* ln_out = nullptr);
+// the same for wide stages (C = 384, mlp_fused_wide.hip): one wave per SIMD, weights as one stream of segments
+bool mlp_fused_wide_supported(int C);
+int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
+                          void* ln_out = nullptr);
 int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
                      hipStream_t s);
 int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, int W, int C, hipStream_t s);

@@ -342,6 +342,47 @@ static int finalize_impl(acx_ctx* c) {
                     ACX_TRY(upload(c, pk, &bw.wpack_s));
                 }
             }
+            if (c->precision == ACX_PREC_F32_SPLIT && c->use_fused_mlp && mlp_fused_wide_supported(C)) {
+                // mlp_fused_wide.hip: ONE stream of 128 C-byte segments in consumption order
+                //   W1(0) W1(1) W2(0) W1(2) W2(1) ... W1(n-1) W2(n-2) W2(n-1),   n = 4C/32 hidden chunks,
+                // each already in LDS image order (XOR swizzles baked in): a 1-KB LDS-DMA piece is 1 KB of the stream.
+                const int nch = 4 * C / 32;
+                const size_t seg = (size_t)64 * C;                   // uint16 elements per segment (128 C bytes)
+                const std::vector<uint16_t> h1 = s16_rows(f1, 4 * C, C, bw.w1s_scale);      // [4C][C/8][hi8 | lo8]
+                std::vector<uint16_t> st((size_t)2 * nch * seg);
+                for (int k = 0; k < nch; ++k) {
+                    // W1 image of chunk k: slab u = channels 128u..+127 (16 KB), row r = hidden unit 32k + r (512 B = 32
+                    // chunks of 16 B), content chunk p (block p >> 1 of the slab row, p & 1: hi / lo halves) at position
+                    // (p & 16) | ((p & 15) ^ (r & 15))
+                    uint16_t* w1img = st.data() + (size_t)(k == 0 ? 0 : 2 * k - 1) * seg;
+                    for (int u = 0; u < C / 128; ++u)
+                        for (int r = 0; r < 32; ++r)
+                            for (int p = 0; p < 32; ++p) {
+                                const int pos = (p & 16) | ((p & 15) ^ (r & 15));
+                                std::memcpy(w1img + ((size_t)u * 16384 + (size_t)r * 512 + (size_t)pos * 16) / 2,
+                                            h1.data() + ((size_t)(32 * k + r) * C * 4 + (size_t)(32 * u + p) * 16) / 2, 16);
+                            }
+                    // W2 image of chunk k: row = out channel (128 B = 8 chunks); content chunk 2b (hi) / 2b + 1 (lo) of
+                    // block b = 2s' + h holds hidden units 32k + 16s' + 4h + 8(jj >> 2) + (jj & 3), at position ^ ((ch >> 1) & 7)
+                    uint16_t* w2img = st.data() + (size_t)(k == nch - 1 ? 2 * nch - 1 : 2 * k + 2) * seg;
+                    for (int ch = 0; ch < C; ++ch)
+                        for (int b = 0; b < 4; ++b) {
+                            uint16_t hi8[8], lo8[8];
+                            for (int jj = 0; jj < 8; ++jj) {
+                                const int u = 32 * k + 16 * (b >> 1) + 4 * (b & 1) + 8 * (jj >> 2) + (jj & 3);
+                                const float v = f2[(size_t)ch * 4 * C + u] * bw.w2s_scale;
+                                const _Float16 hi = (_Float16)v;
+                                const _Float16 lo = (_Float16)(v - (float)hi);
+                                std::memcpy(&hi8[jj], &hi, 2);
+                                std::memcpy(&lo8[jj], &lo, 2);
+                            }
+                            const int sw = (ch >> 1) & 7;
+                            std::memcpy(w2img + ((size_t)ch * 128 + (size_t)((2 * b) ^ sw) * 16) / 2, hi8, 16);
+                            std::memcpy(w2img + ((size_t)ch * 128 + (size_t)((2 * b + 1) ^ sw) * 16) / 2, lo8, 16);
+                        }
+                }
+                ACX_TRY(upload(c, st, &bw.wstream_s));
+            }
             if (mlp_fused_supported(C)) {       // chunk-major image for the fused kernel's LDS-DMA
                 const int nch = 4 * C / 32;
                 std::vector<float> pk((size_t)nch * 64 * C);
@@ -431,7 +472,8 @@ static int run_mlp_split(acx_ctx* c, const BlockW& bw, int C, float* y, float* x
 // True when the last block of stage s can hand the downsample conv its LayerNorm'ed S16 operand directly
 // (fused split MLP kernel, LNOUT epilogue): x of that stage is then NOT updated by its last block.
 static bool block_can_emit_ln(const acx_ctx* c, int s) {
-    return s < 3 && c->precision == ACX_PREC_F32_SPLIT && c->use_fused_mlp && mlp_fused_supported(kDims[s]);
+    return s < 3 && c->precision == ACX_PREC_F32_SPLIT && c->use_fused_mlp &&
+           (mlp_fused_supported(kDims[s]) || mlp_fused_wide_supported(kDims[s]));
 }
 
 static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden, float* stats, int B, int H, int Wd,
@@ -442,6 +484,7 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     if (c->precision == ACX_PREC_F32_SPLIT) {
         ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
         if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused_split(c, bw, C, y, x, M, st, ln_out);
+        if (c->use_fused_mlp && mlp_fused_wide_supported(C)) return launch_mlp_fused_wide(c, bw, C, y, x, M, st, ln_out);
         if (ln_out) ACX_FAIL(ACX_ERR_STATE, "run_block: LayerNorm output requested from a two-GEMM stage");
         return run_mlp_split(c, bw, C, y, x, hidden, M, st);
     }
@@ -647,7 +690,7 @@ static int forward_one(acx_ctx* c, const float* wav, int B, int64_t L, int mode,
     for (int s = 0; s < 4; ++s) {
         if (s > 0) ACX_TRY(run_downsample(c, s, x[s - 1], x[s], y, B, p.Hs[s - 1], p.Ws[s - 1], st, block_can_emit_ln(c, s - 1)));
         for (int j = 0; j < kDepths[s]; ++j) {
-            // the last block of stages 0-1 writes LayerNorm(x) in S16 form into y (the downsample's operand buffer)
+            // the last block of stages 0-2 writes LayerNorm(x) in S16 form into y (the downsample's operand buffer)
             // instead of x: nothing else reads that x (convnext.py:270-273)
             void* ln_out = (j == kDepths[s] - 1 && block_can_emit_ln(c, s)) ? (void*)y : nullptr;
             ACX_TRY(run_block(c, s, j, x[s], y, hidden, stats, B, p.Hs[s], p.Ws[s], st, ln_out));

@@ -1,0 +1,371 @@
+// K4fw -- the fused block MLP (LayerNorm -> pwconv1 -> GELU -> pwconv2 -> gamma -> + residual, convnext.py:77-86) in
+// split-fp16 arithmetic for WIDE stages (C = 384): the hidden activation (B H W x 4C, 347 MB per block at B = 64) never
+// exists in memory (hard part 1).  Same transposed dataflow as mlp_fused_split.hip -- a wave owns 32 pixels,
+// the accumulator tile of the first product is the B operand of the second -- re-planned for one wave per SIMD:
+//
+//   registers   the workgroup is CU-exclusive (acx_internal.h): 4 waves x 512 registers.  Per lane: C/2 for the wave's
+//               normalised activations (hi + lo halves, B operand of phase 1), C/2 accumulators of out^T, ~100 working.
+//   weights     acx_finalize lays every block's weights out as ONE stream of segments in consumption order,
+//                 W1(0) W1(1) W2(0) W1(2) W2(1) ... W1(n-1) W2(n-2) W2(n-1)        (n = 4C/32 hidden chunks)
+//               a segment = the [32 x C] (W1) or [C x 32] (W2) S16 image of one chunk, 128 C bytes, already in LDS image
+//               order (XOR swizzle baked in), so the LDS-DMA source of a piece is base + 1 KB x piece + 16 x lane.
+//               LDS holds a ring of three segments: one being multiplied, one landed or landing, one being requested.
+//   schedule    segment 2k-1: phase 1 of chunk k    X^T[32 hidden x 32 px] = W1c . LN(y)^T     3 C/16 MFMAs on X
+//               segment 2k  : phase 2 of chunk k-1  out^T[C x 32 px] += W2c . G(k-1)            3 C/16 MFMAs
+//                             with GELU + hi/lo split of X(k) -> G(k) dealt over its units (24 pieces of ~9 VALU)
+//               The DMA pieces of segment s+2 are threaded through the units of segment s; one counted s_waitcnt vmcnt +
+//               s_barrier per segment.  Only X, G and G' (48 registers) bridge the two phases.
+// HBM traffic per block: read y, read x, write x (3 C H W 4 bytes) + the weight stream from L2 / MALL.
+#include <type_traits>
+
+#include "acx_internal.h"
+#include "split_math.h"
+
+namespace acx {
+
+template <int C>
+struct WideCfg {
+    static constexpr int kWaves = 4;
+    static constexpr int kThreads = kWaves * 64;
+    static constexpr int kPix = kWaves * 32;
+    static constexpr int kChunks = 4 * C / 32;              // n
+    static constexpr int kSegs = 2 * kChunks;
+    static constexpr int kSegBytes = 128 * C;               // one [32][C] or [C][32] S16 image
+    static constexpr int kPieces = kSegBytes / 1024 / kWaves;   // 1-KB LDS-DMA pieces per wave per segment
+    static constexpr int kSteps = C / 16;                   // units of a phase-1 segment (k-steps)
+    static constexpr int kUnits = 2 * (C / 32);             // units of a phase-2 segment (out tile, k-step)
+    static constexpr int kSlabs = C / 128;                  // a W1 image is kSlabs slabs of [32 hidden][128 channels]
+    static constexpr size_t kLdsBytes = 3 * (size_t)kSegBytes + 4 * C * 4;
+    static_assert(C % 128 == 0 && kSteps == kUnits && kUnits % kPieces == 0 && 24 % kUnits == 0, "unit / piece bookkeeping");
+};
+
+// byte offset of segment s in the stream: order W1(0) W1(1) W2(0) W1(2) W2(1) ... (see the header)
+//   W1(k): k == 0 ? 0 : 2k - 1       W2(k): k == n - 1 ? 2n - 1 : 2k + 2
+template <int C, bool LNOUT>
+__global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
+    const float* __restrict__ y, float* __restrict__ x, const char* __restrict__ wstream /*[2n][128 C bytes]*/,
+    const float* __restrict__ b1, const float* __restrict__ b2, long long M, float sinv1, float sinv2, float hscale,
+    char* __restrict__ ln_out /* LNOUT: (M, C) S16 rows of LayerNorm(x_new) x 2^11, written INSTEAD of x */) {
+    using Cfg = WideCfg<C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* b1s = reinterpret_cast<float*>(smem + 3 * Cfg::kSegBytes);   // [4C], pre-divided by sinv1
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    ACX_CLAIM_VGPR(255);          // CU-exclusive: one wave per SIMD holds the SIMD's whole register file
+    ACX_CLAIM_AGPR(255);
+    const long long pix0 = (long long)blockIdx.x * Cfg::kPix + wave * 32;
+    long long mrow = pix0 + l31;
+    const bool valid = mrow < M;
+    if (!valid) mrow = M - 1;
+
+    constexpr int n = Cfg::kChunks;
+    const int dma_lane = (wave * Cfg::kPieces) * 1024 + lane * 16;      // this lane's slot in piece 0 of its wave
+#define ACX_WDMA(seg_, piece_, grp_)                                                                             \
+        __builtin_amdgcn_global_load_lds(                                                                        \
+            (const __attribute__((address_space(1))) void*)(wstream + (long long)(seg_) * Cfg::kSegBytes + dma_lane + (piece_) * 1024), \
+            (__attribute__((address_space(3))) void*)(smem + (grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_)) * 1024), 16, 0, 0);
+    // segments 0 and 1 are requested before anything else; segment s + 2 follows during segment s
+#pragma unroll
+    for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(0, p, 0)
+#pragma unroll
+    for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(1, p, 1)
+    {
+        const float b1scale = 1.0f / sinv1;             // a power of two
+        for (int i = tid; i < 4 * C; i += Cfg::kThreads) b1s[i] = b1[i] * b1scale;
+    }
+
+    // ---- this wave's activations: lane (px = l31, half hh) holds channels 16s + 8hh .. +7, s = 0..C/16-1 --------
+    f32x4 acth[Cfg::kSteps], actl[Cfg::kSteps];         // 8 fp16 halves each
+    {
+        float a[C / 2];
+        const float* yp = y + mrow * C + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < Cfg::kSteps; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(yp + 16 * s);
+            const float4 v1 = *reinterpret_cast<const float4*>(yp + 16 * s + 4);
+            a[8 * s + 0] = v0.x; a[8 * s + 1] = v0.y; a[8 * s + 2] = v0.z; a[8 * s + 3] = v0.w;
+            a[8 * s + 4] = v1.x; a[8 * s + 5] = v1.y; a[8 * s + 6] = v1.z; a[8 * s + 7] = v1.w;
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) sum += a[i];
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / C);
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) { const float t = a[i] - mean; d = fmaf(t, t, d); }
+        d += __shfl_xor(d, 32);
+        const float sc = kSplitLnScale / sqrtf(d * (1.0f / C) + 1e-6f);
+#pragma unroll
+        for (int s = 0; s < Cfg::kSteps; ++s) {
+            unsigned uh4[4], ul4[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                f32x2 v;
+                v.x = (a[8 * s + 2 * p] - mean) * sc; v.y = (a[8 * s + 2 * p + 1] - mean) * sc;
+                const h2 h = __builtin_convertvector(v, h2);
+                const f32x2 back = __builtin_convertvector(h, f32x2);
+                const h2 l = __builtin_convertvector(v - back, h2);
+                uh4[p] = __builtin_bit_cast(unsigned, h);
+                ul4[p] = __builtin_bit_cast(unsigned, l);
+            }
+            acth[s] = __builtin_bit_cast(f32x4, uint4{uh4[0], uh4[1], uh4[2], uh4[3]});
+            actl[s] = __builtin_bit_cast(f32x4, uint4{ul4[0], ul4[1], ul4[2], ul4[3]});
+        }
+    }
+
+    f32x16 acc[C / 32];
+#pragma unroll
+    for (int t = 0; t < C / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // fragment addresses inside a segment (without the ring offset):
+    //   W1 image: slab u = s / 8 (16 KB), row = hidden unit l31 (512 B = 32 chunks), chunk p = 4 (s % 8) + 2 hh + pl at
+    //             position p ^ (l31 & 15)                       (pl = 0 hi halves, 1 lo halves)
+    //   W2 image: row = out channel (128 B = 8 chunks), tile t rows 32 t + l31, chunk 2 (2 s' + hh) + pl at position ^ ((l31 >> 1) & 7)
+    int w1off[4][2], w2off[2][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) w1off[q][pl] = l31 * 512 + (((4 * q + 2 * hh + pl) ^ (l31 & 15)) << 4);
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) w2off[sp][pl] = l31 * 128 + (((2 * (2 * sp + hh) + pl) ^ ((l31 >> 1) & 7)) << 4);
+    GeluConsts gk;
+    gk.ps = 0.3275911f * 0.70710678f * sinv1;
+    gk.cq = 0.84932180f * sinv1;       // sqrt(log2(e) / 2): exp(-v^2 / 2) = exp2(-(cq a)^2)
+    gk.ca = -0.5f * sinv1 * hscale;
+    gk.cb = sinv1 * hscale;
+
+#define ACX_H8(v_) __builtin_bit_cast(h8, v_)
+#define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
+    // phase-1 unit = k-step s_ of the chunk: slab s_/8, chunk group (s_ % 8): high bit of the chunk index = (s_ % 8) / 4 -> +256 B
+#define ACX_W1_RD(base_, s_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((s_) >> 3) * 16384 + (((s_) >> 2) & 1) * 256 + w1off[(s_) & 3][pl_]))
+#define ACX_P1_MFMA(s_, ah_, al_)                                                                               \
+        X = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[s_]), X, 0, 0, 0);                  \
+        X = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(actl[s_]), X, 0, 0, 0);                  \
+        X = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(acth[s_]), X, 0, 0, 0);
+    // phase-2 unit i = (out tile t = i >> 1, k-step s' = i & 1)
+#define ACX_W2_RD(base_, i_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((i_) >> 1) * 4096 + w2off[(i_) & 1][pl_]))
+#define ACX_P2_MFMA(i_, ah_, al_)                                                                               \
+        acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
+        acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gl[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
+        acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0);
+#define ACX_TOUCH2(h_, l_) { asm volatile("" :: "v"(h_)); asm volatile("" :: "v"(l_)); }
+#define ACX_BIAS_INIT(j_)                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j_) + 8 * q + 4 * hh);                 \
+            X[4 * q + 0] = bq[0]; X[4 * q + 1] = bq[1]; X[4 * q + 2] = bq[2]; X[4 * q + 3] = bq[3];             \
+        }
+    // GELU pieces [first, first + count) of the 24 that turn X into the packed halves uh / ul
+#define ACX_PIECES(first_, count_)                                                                              \
+        _Pragma("unroll") for (int pc_ = (first_); pc_ < (first_) + (count_); ++pc_) {                          \
+            const int pr_ = pc_ / 3, sub_ = pc_ - 3 * pr_;                                                      \
+            f32x2 a2_;                                                                                          \
+            a2_.x = X[2 * pr_]; a2_.y = X[2 * pr_ + 1];                                                         \
+            if (sub_ == 0) gelu_piece1(a2_, gk, s_av[pr_], s_t[pr_], s_e[pr_]);                                 \
+            else if (sub_ == 1) gelu_piece2(a2_, s_av[pr_], s_t[pr_], s_e[pr_], gk, s_g[pr_]);                  \
+            else gelu_piece3(s_g[pr_], uh[pr_], ul[pr_]);                                                       \
+        }
+#define ACX_PACK_G()                                                                                            \
+        gh[0] = __builtin_bit_cast(f32x4, uint4{uh[0], uh[1], uh[2], uh[3]});                                   \
+        gh[1] = __builtin_bit_cast(f32x4, uint4{uh[4], uh[5], uh[6], uh[7]});                                   \
+        gl[0] = __builtin_bit_cast(f32x4, uint4{ul[0], ul[1], ul[2], ul[3]});                                   \
+        gl[1] = __builtin_bit_cast(f32x4, uint4{ul[4], ul[5], ul[6], ul[7]});
+    // end of a segment: the pieces requested during it may stay in flight, everything older must have landed, and
+    // every wave must be done reading the segment before its ring slot is requested again
+#define ACX_SEG_END(issued_)                                                                                    \
+        ACX_FENCE                                                                                               \
+        if (issued_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::kPieces) : "memory");                       \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        ACX_FENCE
+
+    f32x16 X;             // pre-activation of the chunk in flight between its phase 1 and its GELU
+    f32x4 gh[2], gl[2];   // G(k - 1): B operand of phase 2, two k-steps, hi / lo halves
+    f32x2 s_av[8], s_t[8], s_e[8], s_g[8];
+    unsigned uh[8], ul[8];
+    constexpr int kDmaStride = Cfg::kUnits / Cfg::kPieces;       // one piece every kDmaStride units
+    constexpr int kPer = 24 / Cfg::kUnits;                        // GELU pieces per phase-2 unit
+
+    // one phase-1 segment: X = b1 + W1c . LN(y)^T for chunk k_, image in ring slot grp_, requesting segment seg_ + 2
+    auto phase1 = [&](const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
+        const char* base = smem + grp_ * Cfg::kSegBytes;
+        const bool dma = seg_ + 2 < Cfg::kSegs;
+        const int g2 = (grp_ + 2) % 3;
+        ACX_BIAS_INIT(k_)
+        f32x4 a0h = ACX_W1_RD(base, 0, 0), a0l = ACX_W1_RD(base, 0, 1), a1h, a1l;
+#pragma unroll
+        for (int s = 0; s < Cfg::kSteps; s += 2) {
+            a1h = ACX_W1_RD(base, s + 1, 0); a1l = ACX_W1_RD(base, s + 1, 1);
+            ACX_FENCE
+            ACX_P1_MFMA(s, a0h, a0l)
+            if (s % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, s / kDmaStride, g2) }
+            ACX_FENCE
+            ACX_TOUCH2(a1h, a1l)
+            if (s + 2 < Cfg::kSteps) { a0h = ACX_W1_RD(base, s + 2, 0); a0l = ACX_W1_RD(base, s + 2, 1); }
+            ACX_FENCE
+            ACX_P1_MFMA(s + 1, a1h, a1l)
+            if ((s + 1) % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (s + 1) / kDmaStride, g2) }
+            ACX_FENCE
+            if (s + 2 < Cfg::kSteps) ACX_TOUCH2(a0h, a0l)
+        }
+        ACX_SEG_END(dma)
+    };
+    // one phase-2 segment: out^T += W2c . G for the chunk whose G sits in gh / gl, image in ring slot grp_; with_gelu:
+    // the GELU + split of X (the NEXT chunk) is dealt over the units and becomes the new G at the end
+    auto phase2 = [&](auto with_gelu, const int seg_, const int grp_) __attribute__((always_inline)) {
+        constexpr bool HV = decltype(with_gelu)::value;
+        const char* base = smem + grp_ * Cfg::kSegBytes;
+        const bool dma = seg_ + 2 < Cfg::kSegs;
+        const int g2 = (grp_ + 2) % 3;
+        f32x4 a0h = ACX_W2_RD(base, 0, 0), a0l = ACX_W2_RD(base, 0, 1), a1h, a1l;
+#pragma unroll
+        for (int i = 0; i < Cfg::kUnits; i += 2) {
+            a1h = ACX_W2_RD(base, i + 1, 0); a1l = ACX_W2_RD(base, i + 1, 1);
+            ACX_FENCE
+            ACX_P2_MFMA(i, a0h, a0l)
+            if (i % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, i / kDmaStride, g2) }
+            if constexpr (HV) { ACX_PIECES(kPer * i, kPer) }
+            ACX_FENCE
+            ACX_TOUCH2(a1h, a1l)
+            if (i + 2 < Cfg::kUnits) { a0h = ACX_W2_RD(base, i + 2, 0); a0l = ACX_W2_RD(base, i + 2, 1); }
+            ACX_FENCE
+            ACX_P2_MFMA(i + 1, a1h, a1l)
+            if ((i + 1) % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (i + 1) / kDmaStride, g2) }
+            if constexpr (HV) { ACX_PIECES(kPer * (i + 1), kPer) }
+            ACX_FENCE
+            if (i + 2 < Cfg::kUnits) ACX_TOUCH2(a0h, a0l)
+        }
+        if constexpr (HV) { ACX_PACK_G() }
+        ACX_SEG_END(dma)
+    };
+
+    __syncthreads();      // segments 0 and 1 landed (hipcc drains the LDS-DMA before the barrier); b1s visible
+    // segment 0: phase 1 of chunk 0, its GELU with nothing to overlap
+    phase1(0, 0, 0);
+    ACX_PIECES(0, 24)
+    ACX_PACK_G()
+    // segments 2k-1 (phase 1 of chunk k) and 2k (phase 2 of chunk k-1 + GELU of chunk k); ring slot = segment % 3
+    int grp = 1;
+    for (int k = 1; k < n; ++k) {
+        phase1(k, 2 * k - 1, grp);
+        grp = grp == 2 ? 0 : grp + 1;
+        phase2(std::true_type{}, 2 * k, grp);
+        grp = grp == 2 ? 0 : grp + 1;
+    }
+    phase2(std::false_type{}, 2 * n - 1, grp);
+#undef ACX_WDMA
+#undef ACX_H8
+#undef ACX_FENCE
+#undef ACX_W1_RD
+#undef ACX_P1_MFMA
+#undef ACX_W2_RD
+#undef ACX_P2_MFMA
+#undef ACX_TOUCH2
+#undef ACX_BIAS_INIT
+#undef ACX_PIECES
+#undef ACX_PACK_G
+#undef ACX_SEG_END
+
+    // ---- epilogue: lane (px, hh), tile t, q: channels 32t + 8q + 4hh .. +3  ->  x = x + out + b2 ---------
+    if constexpr (LNOUT) {
+        // last block of the stage in the full forward: the only reader of the new x is the LayerNorm in front of the
+        // downsample conv (convnext.py:230-235): write its S16 operand instead (see mlp_fused_split.hip)
+        const float* xp = x + mrow * C + 4 * hh;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < C / 32; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 32 * t + 8 * q;
+                const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
+                const float4 v = *reinterpret_cast<const float4*>(xp + c);
+                acc[t][4 * q + 0] = v.x + fmaf(acc[t][4 * q + 0], sinv2, bb.x);
+                acc[t][4 * q + 1] = v.y + fmaf(acc[t][4 * q + 1], sinv2, bb.y);
+                acc[t][4 * q + 2] = v.z + fmaf(acc[t][4 * q + 2], sinv2, bb.z);
+                acc[t][4 * q + 3] = v.w + fmaf(acc[t][4 * q + 3], sinv2, bb.w);
+                sum += (acc[t][4 * q + 0] + acc[t][4 * q + 1]) + (acc[t][4 * q + 2] + acc[t][4 * q + 3]);
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / C);
+        float d = 0.f;
+#pragma unroll
+        for (int t = 0; t < C / 32; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float u = acc[t][r] - mean; d = fmaf(u, u, d); }
+        d += __shfl_xor(d, 32);
+        const float sc = kSplitLnScale / sqrtf(d * (1.0f / C) + 1e-6f);
+        if (valid) {
+            char* op = ln_out + mrow * (long long)(C * 4) + 8 * hh;
+#pragma unroll
+            for (int t = 0; t < C / 32; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned uhi[2], ulo[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        f32x2 v;
+                        v.x = (acc[t][4 * q + 2 * e] - mean) * sc; v.y = (acc[t][4 * q + 2 * e + 1] - mean) * sc;
+                        const h2 h = __builtin_convertvector(v, h2);
+                        const f32x2 back = __builtin_convertvector(h, f32x2);
+                        const h2 l = __builtin_convertvector(v - back, h2);
+                        uhi[e] = __builtin_bit_cast(unsigned, h);
+                        ulo[e] = __builtin_bit_cast(unsigned, l);
+                    }
+                    char* blk = op + (4 * t + q) * 32;          // channels 32t + 8q .. +7: this lane the half 4hh .. +3
+                    *reinterpret_cast<uint2*>(blk) = uint2{uhi[0], uhi[1]};
+                    *reinterpret_cast<uint2*>(blk + 16) = uint2{ulo[0], ulo[1]};
+                }
+            }
+        }
+    } else if (valid) {
+        float* xp = x + mrow * C + 4 * hh;
+#pragma unroll
+        for (int t = 0; t < C / 32; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 32 * t + 8 * q;
+                const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
+                float4 v = *reinterpret_cast<const float4*>(xp + c);
+                v.x += fmaf(acc[t][4 * q + 0], sinv2, bb.x);
+                v.y += fmaf(acc[t][4 * q + 1], sinv2, bb.y);
+                v.z += fmaf(acc[t][4 * q + 2], sinv2, bb.z);
+                v.w += fmaf(acc[t][4 * q + 3], sinv2, bb.w);
+                *reinterpret_cast<float4*>(xp + c) = v;
+            }
+        }
+    }
+}
+
+template <int C, bool LNOUT>
+static int launch_wide_cfg(const BlockW& w, const float* y, float* x, long long M, void* ln_out, hipStream_t s) {
+    using Cfg = WideCfg<C>;
+    static_assert(Cfg::kLdsBytes <= kCuLdsBytes, "weight ring does not fit the LDS");
+    static DeviceOnce once;
+    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_kernel<C, LNOUT>, kCuLdsBytes));
+    const long long blocks = (M + Cfg::kPix - 1) / Cfg::kPix;
+    mlp_fused_wide_kernel<C, LNOUT><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s>>>(
+        y, x, reinterpret_cast<const char*>(w.wstream_s), w.b1, w.b2, M, 1.0f / (kSplitLnScale * w.w1s_scale),
+        1.0f / (w.hid_scale * w.w2s_scale), w.hid_scale, reinterpret_cast<char*>(ln_out));
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
+bool mlp_fused_wide_supported(int C) { return C == 384; }
+
+int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
+                          void* ln_out) {
+    if (!w.wstream_s) ACX_FAIL(ACX_ERR_STATE, "wide fused MLP: the weight stream was not packed for C=%d", C);
+    ProfScope ps(c, ACX_K_MLP_FUSED, s);
+    if (C == 384) return ln_out ? launch_wide_cfg<384, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<384, false>(w, y, x, M, nullptr, s);
+    ACX_FAIL(ACX_ERR_SHAPE, "wide fused MLP: unsupported channel count %d", C);
+}
+
+}  // namespace acx

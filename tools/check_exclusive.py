@@ -13,7 +13,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "audioset-convnext-inf_amd", "csrc")
 SOURCES = {"gemm_split.hip": "gemm_split_kernel", "mlp_fused_split.hip": "mlp_fused_split_kernel",
-           "gemm_bf16.hip": "gemm_bf16_kernel", "mlp_fused_bf16.hip": "mlp_fused_bf16_kernel"}
+           "mlp_fused_wide.hip": "mlp_fused_wide_kernel", "gemm_bf16.hip": "gemm_bf16_kernel"}
 
 
 def descriptors(path):
