@@ -351,17 +351,15 @@ static int finalize_impl(acx_ctx* c) {
                 const std::vector<uint16_t> h1 = s16_rows(f1, 4 * C, C, bw.w1s_scale);      // [4C][C/8][hi8 | lo8]
                 std::vector<uint16_t> st((size_t)2 * nch * seg);
                 for (int k = 0; k < nch; ++k) {
-                    // W1 image of chunk k: slab u = channels 128u..+127 (16 KB), row r = hidden unit 32k + r (512 B = 32
-                    // chunks of 16 B), content chunk p (block p >> 1 of the slab row, p & 1: hi / lo halves) at position
-                    // (p & 16) | ((p & 15) ^ (r & 15))
+                    // W1 image of chunk k: row r = hidden unit 32k + r (4 C bytes = C/4 chunks of 16 B: chunk p = block p >> 1
+                    // of the row, p & 1: hi / lo halves), content chunk p at position p ^ (r & 15)
                     uint16_t* w1img = st.data() + (size_t)(k == 0 ? 0 : 2 * k - 1) * seg;
-                    for (int u = 0; u < C / 128; ++u)
-                        for (int r = 0; r < 32; ++r)
-                            for (int p = 0; p < 32; ++p) {
-                                const int pos = (p & 16) | ((p & 15) ^ (r & 15));
-                                std::memcpy(w1img + ((size_t)u * 16384 + (size_t)r * 512 + (size_t)pos * 16) / 2,
-                                            h1.data() + ((size_t)(32 * k + r) * C * 4 + (size_t)(32 * u + p) * 16) / 2, 16);
-                            }
+                    for (int r = 0; r < 32; ++r)
+                        for (int p = 0; p < C / 4; ++p) {
+                            const int pos = p ^ (r & 15);
+                            std::memcpy(w1img + ((size_t)r * 4 * C + (size_t)pos * 16) / 2,
+                                        h1.data() + ((size_t)(32 * k + r) * C * 4 + (size_t)p * 16) / 2, 16);
+                        }
                     // W2 image of chunk k: row = out channel (128 B = 8 chunks); content chunk 2b (hi) / 2b + 1 (lo) of
                     // block b = 2s' + h holds hidden units 32k + 16s' + 4h + 8(jj >> 2) + (jj & 3), at position ^ ((ch >> 1) & 7)
                     uint16_t* w2img = st.data() + (size_t)(k == nch - 1 ? 2 * nch - 1 : 2 * k + 2) * seg;
@@ -483,8 +481,8 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     const int64_t M = (int64_t)B * H * Wd;
     if (c->precision == ACX_PREC_F32_SPLIT) {
         ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
+        if (c->use_fused_mlp && mlp_fused_wide_supported(C) && bw.wstream_s) return launch_mlp_fused_wide(c, bw, C, y, x, M, st, ln_out);
         if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused_split(c, bw, C, y, x, M, st, ln_out);
-        if (c->use_fused_mlp && mlp_fused_wide_supported(C)) return launch_mlp_fused_wide(c, bw, C, y, x, M, st, ln_out);
         if (ln_out) ACX_FAIL(ACX_ERR_STATE, "run_block: LayerNorm output requested from a two-GEMM stage");
         return run_mlp_split(c, bw, C, y, x, hidden, M, st);
     }

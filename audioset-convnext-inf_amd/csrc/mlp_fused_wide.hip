@@ -10,11 +10,14 @@
 //               a segment = the [32 x C] (W1) or [C x 32] (W2) S16 image of one chunk, 128 C bytes, already in LDS image
 //               order (XOR swizzle baked in), so the LDS-DMA source of a piece is base + 1 KB x piece + 16 x lane.
 //               LDS holds a ring of three segments: one being multiplied, one landed or landing, one being requested.
-//   schedule    segment 2k-1: phase 1 of chunk k    X^T[32 hidden x 32 px] = W1c . LN(y)^T     3 C/16 MFMAs on X
+//   schedule    segment 2k-1: phase 1 of chunk k    X^T[32 hidden x 32 px] = W1c . LN(y)^T     3 C/16 MFMAs on Xn
 //               segment 2k  : phase 2 of chunk k-1  out^T[C x 32 px] += W2c . G(k-1)            3 C/16 MFMAs
-//                             with GELU + hi/lo split of X(k) -> G(k) dealt over its units (24 pieces of ~9 VALU)
+//               GELU + hi/lo split of X(k) -> G(k): 72 micro-steps of ~6 vector instructions, the first half dealt over
+//               the MFMAs of segment 2k, the second half over those of segment 2k+1 -- one wave per SIMD issues both
+//               streams, and only ~24 cycles of vector issue hide behind an MFMA (MI355X_MICROARCH.md, cycle constants):
+//               measured, all of the GELU inside the phase-2 segment cost 73 of 219 us per tile (tools/run_wide_lab.sh).
 //               The DMA pieces of segment s+2 are threaded through the units of segment s; one counted s_waitcnt vmcnt +
-//               s_barrier per segment.  Only X, G and G' (48 registers) bridge the two phases.
+//               s_barrier per segment.
 // HBM traffic per block: read y, read x, write x (3 C H W 4 bytes) + the weight stream from L2 / MALL.
 #include <type_traits>
 
@@ -34,9 +37,9 @@ struct WideCfg {
     static constexpr int kPieces = kSegBytes / 1024 / kWaves;   // 1-KB LDS-DMA pieces per wave per segment
     static constexpr int kSteps = C / 16;                   // units of a phase-1 segment (k-steps)
     static constexpr int kUnits = 2 * (C / 32);             // units of a phase-2 segment (out tile, k-step)
-    static constexpr int kSlabs = C / 128;                  // a W1 image is kSlabs slabs of [32 hidden][128 channels]
     static constexpr size_t kLdsBytes = 3 * (size_t)kSegBytes + 4 * C * 4;
-    static_assert(C % 128 == 0 && kSteps == kUnits && kUnits % kPieces == 0 && 24 % kUnits == 0, "unit / piece bookkeeping");
+    static constexpr int kMfmas = 3 * kUnits;               // MFMAs per segment
+    static_assert(C % 64 == 0 && kSteps == kUnits && kUnits % kPieces == 0 && (36 % kMfmas == 0 || kMfmas % 36 == 0), "unit / piece bookkeeping");
 };
 
 // byte offset of segment s in the stream: order W1(0) W1(1) W2(0) W1(2) W2(1) ... (see the header)
@@ -124,14 +127,14 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // fragment addresses inside a segment (without the ring offset):
-    //   W1 image: slab u = s / 8 (16 KB), row = hidden unit l31 (512 B = 32 chunks), chunk p = 4 (s % 8) + 2 hh + pl at
-    //             position p ^ (l31 & 15)                       (pl = 0 hi halves, 1 lo halves)
+    //   W1 image: row = hidden unit l31 (4 C bytes = C/4 chunks of 16 B), chunk p = 4 s + 2 hh + pl at position p ^ (l31 & 15)
+    //             (pl = 0 hi halves, 1 lo halves; the XOR touches the low 4 bits only and C/4 is a multiple of 16)
     //   W2 image: row = out channel (128 B = 8 chunks), tile t rows 32 t + l31, chunk 2 (2 s' + hh) + pl at position ^ ((l31 >> 1) & 7)
     int w1off[4][2], w2off[2][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) w1off[q][pl] = l31 * 512 + (((4 * q + 2 * hh + pl) ^ (l31 & 15)) << 4);
+        for (int pl = 0; pl < 2; ++pl) w1off[q][pl] = l31 * (4 * C) + (((4 * q + 2 * hh + pl) ^ (l31 & 15)) << 4);
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
@@ -144,33 +147,48 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
 
 #define ACX_H8(v_) __builtin_bit_cast(h8, v_)
 #define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
-    // phase-1 unit = k-step s_ of the chunk: slab s_/8, chunk group (s_ % 8): high bit of the chunk index = (s_ % 8) / 4 -> +256 B
-#define ACX_W1_RD(base_, s_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((s_) >> 3) * 16384 + (((s_) >> 2) & 1) * 256 + w1off[(s_) & 3][pl_]))
+    // phase-1 unit = k-step s_ of the chunk: chunk 4 s_ + ..: the bits above the XORed four = s_ / 4 -> + 256 B each
+#define ACX_W1_RD(base_, s_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((s_) >> 2) * 256 + w1off[(s_) & 3][pl_]))
+    // MFMA number m_ of a segment is followed (behind a scheduling fence) by its share of the 36 GELU micro-steps the
+    // segment carries: steps [36 m / kMfmas, 36 (m + 1) / kMfmas) of the half (C = 384: one after every other MFMA,
+    // C = 192: one after each)
+#define ACX_AFTER_MFMA(HV_, half_, m_)                                                                          \
+        ACX_FENCE if constexpr (HV_) { ACX_MICRO_RANGE(36 * (half_) + 36 * (m_) / Cfg::kMfmas, 36 * (half_) + 36 * ((m_) + 1) / Cfg::kMfmas) } ACX_FENCE
 #define ACX_P1_MFMA(s_, ah_, al_)                                                                               \
-        X = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[s_]), X, 0, 0, 0);                  \
-        X = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(actl[s_]), X, 0, 0, 0);                  \
-        X = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(acth[s_]), X, 0, 0, 0);
+        Xn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[s_]), Xn, 0, 0, 0);                \
+        ACX_AFTER_MFMA(HV, 1, 3 * (s_) + 0)                                                                     \
+        Xn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(actl[s_]), Xn, 0, 0, 0);                \
+        ACX_AFTER_MFMA(HV, 1, 3 * (s_) + 1)                                                                     \
+        Xn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(acth[s_]), Xn, 0, 0, 0);                \
+        ACX_AFTER_MFMA(HV, 1, 3 * (s_) + 2)
     // phase-2 unit i = (out tile t = i >> 1, k-step s' = i & 1)
 #define ACX_W2_RD(base_, i_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((i_) >> 1) * 4096 + w2off[(i_) & 1][pl_]))
 #define ACX_P2_MFMA(i_, ah_, al_)                                                                               \
         acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
+        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 0)                                                                     \
         acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gl[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
-        acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0);
+        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 1)                                                                     \
+        acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
+        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 2)
+    // micro-steps [from, to) of the 72 (8 register pairs x 9 steps) that turn Xv into uh / ul
+#define ACX_MICRO_RANGE(from_, to_)                                                                             \
+        _Pragma("unroll") for (int mm_ = (from_); mm_ < (to_); ++mm_) {                                         \
+            const int pr_ = mm_ / 9, st_ = mm_ - 9 * pr_;                                                       \
+            if (st_ == 0) { gs.ax = Xv[2 * pr_]; gs.ay = Xv[2 * pr_ + 1]; gelu_micro<0>(gs, gk, uh[pr_], ul[pr_]); } \
+            else if (st_ == 1) gelu_micro<1>(gs, gk, uh[pr_], ul[pr_]);                                         \
+            else if (st_ == 2) gelu_micro<2>(gs, gk, uh[pr_], ul[pr_]);                                         \
+            else if (st_ == 3) gelu_micro<3>(gs, gk, uh[pr_], ul[pr_]);                                         \
+            else if (st_ == 4) gelu_micro<4>(gs, gk, uh[pr_], ul[pr_]);                                         \
+            else if (st_ == 5) gelu_micro<5>(gs, gk, uh[pr_], ul[pr_]);                                         \
+            else if (st_ == 6) gelu_micro<6>(gs, gk, uh[pr_], ul[pr_]);                                         \
+            else if (st_ == 7) gelu_micro<7>(gs, gk, uh[pr_], ul[pr_]);                                         \
+            else gelu_micro<8>(gs, gk, uh[pr_], ul[pr_]);                                                       \
+        }
 #define ACX_TOUCH2(h_, l_) { asm volatile("" :: "v"(h_)); asm volatile("" :: "v"(l_)); }
 #define ACX_BIAS_INIT(j_)                                                                                       \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
             const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j_) + 8 * q + 4 * hh);                 \
-            X[4 * q + 0] = bq[0]; X[4 * q + 1] = bq[1]; X[4 * q + 2] = bq[2]; X[4 * q + 3] = bq[3];             \
-        }
-    // GELU pieces [first, first + count) of the 24 that turn X into the packed halves uh / ul
-#define ACX_PIECES(first_, count_)                                                                              \
-        _Pragma("unroll") for (int pc_ = (first_); pc_ < (first_) + (count_); ++pc_) {                          \
-            const int pr_ = pc_ / 3, sub_ = pc_ - 3 * pr_;                                                      \
-            f32x2 a2_;                                                                                          \
-            a2_.x = X[2 * pr_]; a2_.y = X[2 * pr_ + 1];                                                         \
-            if (sub_ == 0) gelu_piece1(a2_, gk, s_av[pr_], s_t[pr_], s_e[pr_]);                                 \
-            else if (sub_ == 1) gelu_piece2(a2_, s_av[pr_], s_t[pr_], s_e[pr_], gk, s_g[pr_]);                  \
-            else gelu_piece3(s_g[pr_], uh[pr_], ul[pr_]);                                                       \
+            Xn[4 * q + 0] = bq[0]; Xn[4 * q + 1] = bq[1]; Xn[4 * q + 2] = bq[2]; Xn[4 * q + 3] = bq[3];         \
         }
 #define ACX_PACK_G()                                                                                            \
         gh[0] = __builtin_bit_cast(f32x4, uint4{uh[0], uh[1], uh[2], uh[3]});                                   \
@@ -186,15 +204,15 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
         __builtin_amdgcn_s_barrier();                                                                           \
         ACX_FENCE
 
-    f32x16 X;             // pre-activation of the chunk in flight between its phase 1 and its GELU
+    f32x16 Xn, Xv;        // Xn: pre-activation being accumulated by phase 1; Xv: the previous chunk's, input of the GELU
     f32x4 gh[2], gl[2];   // G(k - 1): B operand of phase 2, two k-steps, hi / lo halves
-    f32x2 s_av[8], s_t[8], s_e[8], s_g[8];
     unsigned uh[8], ul[8];
     constexpr int kDmaStride = Cfg::kUnits / Cfg::kPieces;       // one piece every kDmaStride units
-    constexpr int kPer = 24 / Cfg::kUnits;                        // GELU pieces per phase-2 unit
+    GeluState gs;
 
     // one phase-1 segment: X = b1 + W1c . LN(y)^T for chunk k_, image in ring slot grp_, requesting segment seg_ + 2
-    auto phase1 = [&](const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
+    auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
+        constexpr bool HV = decltype(with_gelu)::value;     // second half of the GELU of Xv rides on this segment's MFMAs
         const char* base = smem + grp_ * Cfg::kSegBytes;
         const bool dma = seg_ + 2 < Cfg::kSegs;
         const int g2 = (grp_ + 2) % 3;
@@ -215,10 +233,12 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
             ACX_FENCE
             if (s + 2 < Cfg::kSteps) ACX_TOUCH2(a0h, a0l)
         }
+        if constexpr (HV) { ACX_PACK_G() }
+        Xv = Xn;
         ACX_SEG_END(dma)
     };
     // one phase-2 segment: out^T += W2c . G for the chunk whose G sits in gh / gl, image in ring slot grp_; with_gelu:
-    // the GELU + split of X (the NEXT chunk) is dealt over the units and becomes the new G at the end
+    // the first half of the GELU + split of Xv (the NEXT chunk) rides on this segment's MFMAs
     auto phase2 = [&](auto with_gelu, const int seg_, const int grp_) __attribute__((always_inline)) {
         constexpr bool HV = decltype(with_gelu)::value;
         const char* base = smem + grp_ * Cfg::kSegBytes;
@@ -231,34 +251,33 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
             ACX_FENCE
             ACX_P2_MFMA(i, a0h, a0l)
             if (i % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, i / kDmaStride, g2) }
-            if constexpr (HV) { ACX_PIECES(kPer * i, kPer) }
             ACX_FENCE
             ACX_TOUCH2(a1h, a1l)
             if (i + 2 < Cfg::kUnits) { a0h = ACX_W2_RD(base, i + 2, 0); a0l = ACX_W2_RD(base, i + 2, 1); }
             ACX_FENCE
             ACX_P2_MFMA(i + 1, a1h, a1l)
             if ((i + 1) % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (i + 1) / kDmaStride, g2) }
-            if constexpr (HV) { ACX_PIECES(kPer * (i + 1), kPer) }
             ACX_FENCE
             if (i + 2 < Cfg::kUnits) ACX_TOUCH2(a0h, a0l)
         }
-        if constexpr (HV) { ACX_PACK_G() }
         ACX_SEG_END(dma)
     };
 
     __syncthreads();      // segments 0 and 1 landed (hipcc drains the LDS-DMA before the barrier); b1s visible
-    // segment 0: phase 1 of chunk 0, its GELU with nothing to overlap
-    phase1(0, 0, 0);
-    ACX_PIECES(0, 24)
-    ACX_PACK_G()
-    // segments 2k-1 (phase 1 of chunk k) and 2k (phase 2 of chunk k-1 + GELU of chunk k); ring slot = segment % 3
+    // segment 0: phase 1 of chunk 0; the first half of its GELU has nothing to ride on
+    phase1(std::false_type{}, 0, 0, 0);
+    ACX_MICRO_RANGE(0, 36)
+    // segments 2k-1 (phase 1 of chunk k + second half of GELU(k-1)) and 2k (phase 2 of chunk k-1 + first half of GELU(k));
+    // ring slot = segment % 3
     int grp = 1;
     for (int k = 1; k < n; ++k) {
-        phase1(k, 2 * k - 1, grp);
+        phase1(std::true_type{}, k, 2 * k - 1, grp);
         grp = grp == 2 ? 0 : grp + 1;
         phase2(std::true_type{}, 2 * k, grp);
         grp = grp == 2 ? 0 : grp + 1;
     }
+    ACX_MICRO_RANGE(36, 72)         // second half of the last chunk's GELU: no phase-1 segment left to ride on
+    ACX_PACK_G()
     phase2(std::false_type{}, 2 * n - 1, grp);
 #undef ACX_WDMA
 #undef ACX_H8
@@ -269,7 +288,8 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
 #undef ACX_P2_MFMA
 #undef ACX_TOUCH2
 #undef ACX_BIAS_INIT
-#undef ACX_PIECES
+#undef ACX_MICRO_RANGE
+#undef ACX_AFTER_MFMA
 #undef ACX_PACK_G
 #undef ACX_SEG_END
 
@@ -358,13 +378,14 @@ static int launch_wide_cfg(const BlockW& w, const float* y, float* x, long long 
     return ACX_OK;
 }
 
-bool mlp_fused_wide_supported(int C) { return C == 384; }
+bool mlp_fused_wide_supported(int C) { return C == 384 || C == 192; }
 
 int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
                           void* ln_out) {
     if (!w.wstream_s) ACX_FAIL(ACX_ERR_STATE, "wide fused MLP: the weight stream was not packed for C=%d", C);
     ProfScope ps(c, ACX_K_MLP_FUSED, s);
     if (C == 384) return ln_out ? launch_wide_cfg<384, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<384, false>(w, y, x, M, nullptr, s);
+    if (C == 192) return ln_out ? launch_wide_cfg<192, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<192, false>(w, y, x, M, nullptr, s);
     ACX_FAIL(ACX_ERR_SHAPE, "wide fused MLP: unsupported channel count %d", C);
 }
 
