@@ -352,11 +352,12 @@ static int finalize_impl(acx_ctx* c) {
                 std::vector<uint16_t> st((size_t)2 * nch * seg);
                 for (int k = 0; k < nch; ++k) {
                     // W1 image of chunk k: row r = hidden unit 32k + r (4 C bytes = C/4 chunks of 16 B: chunk p = block p >> 1
-                    // of the row, p & 1: hi / lo halves), content chunk p at position p ^ (r & 15)
+                    // of the row, p & 1: hi / lo halves), content chunk p at position p ^ swz(r): r & 15 when C/4 is a multiple
+                    // of 16 chunks, (r >> 1) & 7 for C = 96 (24 chunks per row: odd rows start 8 chunks further)
                     uint16_t* w1img = st.data() + (size_t)(k == 0 ? 0 : 2 * k - 1) * seg;
                     for (int r = 0; r < 32; ++r)
                         for (int p = 0; p < C / 4; ++p) {
-                            const int pos = p ^ (r & 15);
+                            const int pos = p ^ ((C % 64 == 0) ? (r & 15) : ((r >> 1) & 7));
                             std::memcpy(w1img + ((size_t)r * 4 * C + (size_t)pos * 16) / 2,
                                         h1.data() + ((size_t)(32 * k + r) * C * 4 + (size_t)p * 16) / 2, 16);
                         }

@@ -26,11 +26,15 @@
 
 namespace acx {
 
-template <int C>
+// PT = pixel tiles (of 32) per wave: every weight fragment read from LDS feeds PT x 3 MFMAs.  Shipped with PT = 1.
+// Measured for C = 96 (stage 0), where a segment is only 18 MFMAs per pixel tile against the fixed cost of a segment
+// (three LDS-DMA issues, the barrier) and 36 GELU micro-steps: PT = 2 is correct (parity suite green) but runs 647 us per
+// block against 595 for the 8-wave mlp_fused_split_kernel<96>, which therefore keeps stage 0.
+template <int C, int PT>
 struct WideCfg {
     static constexpr int kWaves = 4;
     static constexpr int kThreads = kWaves * 64;
-    static constexpr int kPix = kWaves * 32;
+    static constexpr int kPix = kWaves * 32 * PT;
     static constexpr int kChunks = 4 * C / 32;              // n
     static constexpr int kSegs = 2 * kChunks;
     static constexpr int kSegBytes = 128 * C;               // one [32][C] or [C][32] S16 image
@@ -38,18 +42,21 @@ struct WideCfg {
     static constexpr int kSteps = C / 16;                   // units of a phase-1 segment (k-steps)
     static constexpr int kUnits = 2 * (C / 32);             // units of a phase-2 segment (out tile, k-step)
     static constexpr size_t kLdsBytes = 3 * (size_t)kSegBytes + 4 * C * 4;
-    static constexpr int kMfmas = 3 * kUnits;               // MFMAs per segment
-    static_assert(C % 64 == 0 && kSteps == kUnits && kUnits % kPieces == 0 && (36 % kMfmas == 0 || kMfmas % 36 == 0), "unit / piece bookkeeping");
+    static constexpr int kMfmas = 3 * kUnits * PT;          // MFMAs per segment
+    static constexpr int kHalf = 36 * PT;                   // GELU micro-steps a segment carries (half of the 72 per pixel tile)
+    static_assert(C % 32 == 0 && kSteps == kUnits && kUnits % kPieces == 0 && (kHalf % kMfmas == 0 || kMfmas % kHalf == 0), "unit / piece bookkeeping");
+    // W1 rows are 4 C bytes: the XOR that spreads 16 consecutive rows over the LDS banks (api.hip packs the image with it)
+    __device__ static int swz1(int row) { return (C % 64 == 0) ? (row & 15) : ((row >> 1) & 7); }
 };
 
 // byte offset of segment s in the stream: order W1(0) W1(1) W2(0) W1(2) W2(1) ... (see the header)
 //   W1(k): k == 0 ? 0 : 2k - 1       W2(k): k == n - 1 ? 2n - 1 : 2k + 2
-template <int C, bool LNOUT>
-__global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
+template <int C, int PT, bool LNOUT>
+__global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     const float* __restrict__ y, float* __restrict__ x, const char* __restrict__ wstream /*[2n][128 C bytes]*/,
     const float* __restrict__ b1, const float* __restrict__ b2, long long M, float sinv1, float sinv2, float hscale,
     char* __restrict__ ln_out /* LNOUT: (M, C) S16 rows of LayerNorm(x_new) x 2^11, written INSTEAD of x */) {
-    using Cfg = WideCfg<C>;
+    using Cfg = WideCfg<C, PT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* b1s = reinterpret_cast<float*>(smem + 3 * Cfg::kSegBytes);   // [4C], pre-divided by sinv1
 
@@ -59,10 +66,14 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
     const int l31 = lane & 31, hh = lane >> 5;
     ACX_CLAIM_VGPR(255);          // CU-exclusive: one wave per SIMD holds the SIMD's whole register file
     ACX_CLAIM_AGPR(255);
-    const long long pix0 = (long long)blockIdx.x * Cfg::kPix + wave * 32;
-    long long mrow = pix0 + l31;
-    const bool valid = mrow < M;
-    if (!valid) mrow = M - 1;
+    long long mrow[PT];           // this lane's pixel row in each of the wave's pixel tiles
+    bool valid[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        mrow[pt] = (long long)blockIdx.x * Cfg::kPix + (wave * PT + pt) * 32 + l31;
+        valid[pt] = mrow[pt] < M;
+        if (!valid[pt]) mrow[pt] = M - 1;
+    }
 
     constexpr int n = Cfg::kChunks;
     const int dma_lane = (wave * Cfg::kPieces) * 1024 + lane * 16;      // this lane's slot in piece 0 of its wave
@@ -81,10 +92,11 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
     }
 
     // ---- this wave's activations: lane (px = l31, half hh) holds channels 16s + 8hh .. +7, s = 0..C/16-1 --------
-    f32x4 acth[Cfg::kSteps], actl[Cfg::kSteps];         // 8 fp16 halves each
-    {
+    f32x4 acth[PT][Cfg::kSteps], actl[PT][Cfg::kSteps];         // 8 fp16 halves each
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
         float a[C / 2];
-        const float* yp = y + mrow * C + 8 * hh;
+        const float* yp = y + mrow[pt] * C + 8 * hh;
 #pragma unroll
         for (int s = 0; s < Cfg::kSteps; ++s) {
             const float4 v0 = *reinterpret_cast<const float4*>(yp + 16 * s);
@@ -115,26 +127,28 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
                 uh4[p] = __builtin_bit_cast(unsigned, h);
                 ul4[p] = __builtin_bit_cast(unsigned, l);
             }
-            acth[s] = __builtin_bit_cast(f32x4, uint4{uh4[0], uh4[1], uh4[2], uh4[3]});
-            actl[s] = __builtin_bit_cast(f32x4, uint4{ul4[0], ul4[1], ul4[2], ul4[3]});
+            acth[pt][s] = __builtin_bit_cast(f32x4, uint4{uh4[0], uh4[1], uh4[2], uh4[3]});
+            actl[pt][s] = __builtin_bit_cast(f32x4, uint4{ul4[0], ul4[1], ul4[2], ul4[3]});
         }
     }
 
-    f32x16 acc[C / 32];
+    f32x16 acc[PT][C / 32];
 #pragma unroll
-    for (int t = 0; t < C / 32; ++t)
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < C / 32; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pt][t][r] = 0.f;
 
     // fragment addresses inside a segment (without the ring offset):
-    //   W1 image: row = hidden unit l31 (4 C bytes = C/4 chunks of 16 B), chunk p = 4 s + 2 hh + pl at position p ^ (l31 & 15)
-    //             (pl = 0 hi halves, 1 lo halves; the XOR touches the low 4 bits only and C/4 is a multiple of 16)
+    //   W1 image: row = hidden unit l31 (4 C bytes = C/4 chunks of 16 B), chunk p = 4 s + 2 hh + pl at position p ^ swz1(l31)
+    //             (pl = 0 hi halves, 1 lo halves; the XOR touches the low 4 (C = 96: 3) bits only)
     //   W2 image: row = out channel (128 B = 8 chunks), tile t rows 32 t + l31, chunk 2 (2 s' + hh) + pl at position ^ ((l31 >> 1) & 7)
     int w1off[4][2], w2off[2][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) w1off[q][pl] = l31 * (4 * C) + (((4 * q + 2 * hh + pl) ^ (l31 & 15)) << 4);
+        for (int pl = 0; pl < 2; ++pl) w1off[q][pl] = l31 * (4 * C) + (((4 * q + 2 * hh + pl) ^ Cfg::swz1(l31)) << 4);
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
@@ -149,52 +163,63 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
 #define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
     // phase-1 unit = k-step s_ of the chunk: chunk 4 s_ + ..: the bits above the XORed four = s_ / 4 -> + 256 B each
 #define ACX_W1_RD(base_, s_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((s_) >> 2) * 256 + w1off[(s_) & 3][pl_]))
-    // MFMA number m_ of a segment is followed (behind a scheduling fence) by its share of the 36 GELU micro-steps the
-    // segment carries: steps [36 m / kMfmas, 36 (m + 1) / kMfmas) of the half (C = 384: one after every other MFMA,
-    // C = 192: one after each)
+    // MFMA number m_ of a segment is followed (behind a scheduling fence) by its share of the kHalf GELU micro-steps the
+    // segment carries: steps [kHalf m / kMfmas, kHalf (m + 1) / kMfmas) of the half (C = 384: one after every other MFMA,
+    // C = 192: one after each, C = 96: two after each)
 #define ACX_AFTER_MFMA(HV_, half_, m_)                                                                          \
-        ACX_FENCE if constexpr (HV_) { ACX_MICRO_RANGE(36 * (half_) + 36 * (m_) / Cfg::kMfmas, 36 * (half_) + 36 * ((m_) + 1) / Cfg::kMfmas) } ACX_FENCE
+        ACX_FENCE if constexpr (HV_) { ACX_MICRO_RANGE(half_, Cfg::kHalf * (m_) / Cfg::kMfmas, Cfg::kHalf * ((m_) + 1) / Cfg::kMfmas) } ACX_FENCE
+    // the three terms of a unit, each over the PT pixel tiles (independent accumulators back to back)
 #define ACX_P1_MFMA(s_, ah_, al_)                                                                               \
-        Xn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[s_]), Xn, 0, 0, 0);                \
-        ACX_AFTER_MFMA(HV, 1, 3 * (s_) + 0)                                                                     \
-        Xn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(actl[s_]), Xn, 0, 0, 0);                \
-        ACX_AFTER_MFMA(HV, 1, 3 * (s_) + 1)                                                                     \
-        Xn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(acth[s_]), Xn, 0, 0, 0);                \
-        ACX_AFTER_MFMA(HV, 1, 3 * (s_) + 2)
+        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
+            Xn[pt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[pt_][s_]), Xn[pt_], 0, 0, 0); \
+            ACX_AFTER_MFMA(HV, 1, (3 * (s_) + 0) * PT + pt_) }                                                  \
+        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
+            Xn[pt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(actl[pt_][s_]), Xn[pt_], 0, 0, 0); \
+            ACX_AFTER_MFMA(HV, 1, (3 * (s_) + 1) * PT + pt_) }                                                  \
+        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
+            Xn[pt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(acth[pt_][s_]), Xn[pt_], 0, 0, 0); \
+            ACX_AFTER_MFMA(HV, 1, (3 * (s_) + 2) * PT + pt_) }
     // phase-2 unit i = (out tile t = i >> 1, k-step s' = i & 1)
 #define ACX_W2_RD(base_, i_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((i_) >> 1) * 4096 + w2off[(i_) & 1][pl_]))
 #define ACX_P2_MFMA(i_, ah_, al_)                                                                               \
-        acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
-        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 0)                                                                     \
-        acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gl[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
-        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 1)                                                                     \
-        acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
-        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 2)
-    // micro-steps [from, to) of the 72 (8 register pairs x 9 steps) that turn Xv into uh / ul
-#define ACX_MICRO_RANGE(from_, to_)                                                                             \
-        _Pragma("unroll") for (int mm_ = (from_); mm_ < (to_); ++mm_) {                                         \
+        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
+            acc[pt_][(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(gh[pt_][(i_) & 1]), acc[pt_][(i_) >> 1], 0, 0, 0); \
+            ACX_AFTER_MFMA(HV, 0, (3 * (i_) + 0) * PT + pt_) }                                                  \
+        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
+            acc[pt_][(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gl[pt_][(i_) & 1]), acc[pt_][(i_) >> 1], 0, 0, 0); \
+            ACX_AFTER_MFMA(HV, 0, (3 * (i_) + 1) * PT + pt_) }                                                  \
+        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
+            acc[pt_][(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[pt_][(i_) & 1]), acc[pt_][(i_) >> 1], 0, 0, 0); \
+            ACX_AFTER_MFMA(HV, 0, (3 * (i_) + 2) * PT + pt_) }
+    // micro-steps [from, to) of the kHalf that segment half half_ carries: step sg_ belongs to pixel tile sg_ / 36 and is
+    // step 36 half_ + sg_ % 36 of the 72 (8 register pairs x 9 steps) that turn that tile's Xv into its uh / ul
+#define ACX_MICRO_RANGE(half_, from_, to_)                                                                      \
+        _Pragma("unroll") for (int sg_ = (from_); sg_ < (to_); ++sg_) {                                         \
+            const int mt_ = sg_ / 36, mm_ = 36 * (half_) + sg_ % 36;                                            \
             const int pr_ = mm_ / 9, st_ = mm_ - 9 * pr_;                                                       \
-            if (st_ == 0) { gs.ax = Xv[2 * pr_]; gs.ay = Xv[2 * pr_ + 1]; gelu_micro<0>(gs, gk, uh[pr_], ul[pr_]); } \
-            else if (st_ == 1) gelu_micro<1>(gs, gk, uh[pr_], ul[pr_]);                                         \
-            else if (st_ == 2) gelu_micro<2>(gs, gk, uh[pr_], ul[pr_]);                                         \
-            else if (st_ == 3) gelu_micro<3>(gs, gk, uh[pr_], ul[pr_]);                                         \
-            else if (st_ == 4) gelu_micro<4>(gs, gk, uh[pr_], ul[pr_]);                                         \
-            else if (st_ == 5) gelu_micro<5>(gs, gk, uh[pr_], ul[pr_]);                                         \
-            else if (st_ == 6) gelu_micro<6>(gs, gk, uh[pr_], ul[pr_]);                                         \
-            else if (st_ == 7) gelu_micro<7>(gs, gk, uh[pr_], ul[pr_]);                                         \
-            else gelu_micro<8>(gs, gk, uh[pr_], ul[pr_]);                                                       \
+            if (st_ == 0) { gs.ax = Xv[mt_][2 * pr_]; gs.ay = Xv[mt_][2 * pr_ + 1]; gelu_micro<0>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]); } \
+            else if (st_ == 1) gelu_micro<1>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
+            else if (st_ == 2) gelu_micro<2>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
+            else if (st_ == 3) gelu_micro<3>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
+            else if (st_ == 4) gelu_micro<4>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
+            else if (st_ == 5) gelu_micro<5>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
+            else if (st_ == 6) gelu_micro<6>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
+            else if (st_ == 7) gelu_micro<7>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
+            else gelu_micro<8>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                                             \
         }
 #define ACX_TOUCH2(h_, l_) { asm volatile("" :: "v"(h_)); asm volatile("" :: "v"(l_)); }
 #define ACX_BIAS_INIT(j_)                                                                                       \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
             const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j_) + 8 * q + 4 * hh);                 \
-            Xn[4 * q + 0] = bq[0]; Xn[4 * q + 1] = bq[1]; Xn[4 * q + 2] = bq[2]; Xn[4 * q + 3] = bq[3];         \
+            _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                              \
+                Xn[pt_][4 * q + 0] = bq[0]; Xn[pt_][4 * q + 1] = bq[1]; Xn[pt_][4 * q + 2] = bq[2]; Xn[pt_][4 * q + 3] = bq[3]; } \
         }
 #define ACX_PACK_G()                                                                                            \
-        gh[0] = __builtin_bit_cast(f32x4, uint4{uh[0], uh[1], uh[2], uh[3]});                                   \
-        gh[1] = __builtin_bit_cast(f32x4, uint4{uh[4], uh[5], uh[6], uh[7]});                                   \
-        gl[0] = __builtin_bit_cast(f32x4, uint4{ul[0], ul[1], ul[2], ul[3]});                                   \
-        gl[1] = __builtin_bit_cast(f32x4, uint4{ul[4], ul[5], ul[6], ul[7]});
+        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
+            gh[pt_][0] = __builtin_bit_cast(f32x4, uint4{uh[pt_][0], uh[pt_][1], uh[pt_][2], uh[pt_][3]});      \
+            gh[pt_][1] = __builtin_bit_cast(f32x4, uint4{uh[pt_][4], uh[pt_][5], uh[pt_][6], uh[pt_][7]});      \
+            gl[pt_][0] = __builtin_bit_cast(f32x4, uint4{ul[pt_][0], ul[pt_][1], ul[pt_][2], ul[pt_][3]});      \
+            gl[pt_][1] = __builtin_bit_cast(f32x4, uint4{ul[pt_][4], ul[pt_][5], ul[pt_][6], ul[pt_][7]}); }
     // end of a segment: the pieces requested during it may stay in flight, everything older must have landed, and
     // every wave must be done reading the segment before its ring slot is requested again
 #define ACX_SEG_END(issued_)                                                                                    \
@@ -204,9 +229,9 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
         __builtin_amdgcn_s_barrier();                                                                           \
         ACX_FENCE
 
-    f32x16 Xn, Xv;        // Xn: pre-activation being accumulated by phase 1; Xv: the previous chunk's, input of the GELU
-    f32x4 gh[2], gl[2];   // G(k - 1): B operand of phase 2, two k-steps, hi / lo halves
-    unsigned uh[8], ul[8];
+    f32x16 Xn[PT], Xv[PT];        // Xn: pre-activation being accumulated by phase 1; Xv: the previous chunk's, input of the GELU
+    f32x4 gh[PT][2], gl[PT][2];   // G(k - 1): B operand of phase 2, two k-steps, hi / lo halves
+    unsigned uh[PT][8], ul[PT][8];
     constexpr int kDmaStride = Cfg::kUnits / Cfg::kPieces;       // one piece every kDmaStride units
     GeluState gs;
 
@@ -234,7 +259,8 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
             if (s + 2 < Cfg::kSteps) ACX_TOUCH2(a0h, a0l)
         }
         if constexpr (HV) { ACX_PACK_G() }
-        Xv = Xn;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) Xv[pt] = Xn[pt];
         ACX_SEG_END(dma)
     };
     // one phase-2 segment: out^T += W2c . G for the chunk whose G sits in gh / gl, image in ring slot grp_; with_gelu:
@@ -266,7 +292,7 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
     __syncthreads();      // segments 0 and 1 landed (hipcc drains the LDS-DMA before the barrier); b1s visible
     // segment 0: phase 1 of chunk 0; the first half of its GELU has nothing to ride on
     phase1(std::false_type{}, 0, 0, 0);
-    ACX_MICRO_RANGE(0, 36)
+    ACX_MICRO_RANGE(0, 0, Cfg::kHalf)
     // segments 2k-1 (phase 1 of chunk k + second half of GELU(k-1)) and 2k (phase 2 of chunk k-1 + first half of GELU(k));
     // ring slot = segment % 3
     int grp = 1;
@@ -276,7 +302,7 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
         phase2(std::true_type{}, 2 * k, grp);
         grp = grp == 2 ? 0 : grp + 1;
     }
-    ACX_MICRO_RANGE(36, 72)         // second half of the last chunk's GELU: no phase-1 segment left to ride on
+    ACX_MICRO_RANGE(1, 0, Cfg::kHalf)       // second half of the last chunk's GELU: no phase-1 segment left to ride on
     ACX_PACK_G()
     phase2(std::false_type{}, 2 * n - 1, grp);
 #undef ACX_WDMA
@@ -294,10 +320,12 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
 #undef ACX_SEG_END
 
     // ---- epilogue: lane (px, hh), tile t, q: channels 32t + 8q + 4hh .. +3  ->  x = x + out + b2 ---------
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
     if constexpr (LNOUT) {
         // last block of the stage in the full forward: the only reader of the new x is the LayerNorm in front of the
         // downsample conv (convnext.py:230-235): write its S16 operand instead (see mlp_fused_split.hip)
-        const float* xp = x + mrow * C + 4 * hh;
+        const float* xp = x + mrow[pt] * C + 4 * hh;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < C / 32; ++t) {
@@ -306,11 +334,11 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
                 const int c = 32 * t + 8 * q;
                 const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
                 const float4 v = *reinterpret_cast<const float4*>(xp + c);
-                acc[t][4 * q + 0] = v.x + fmaf(acc[t][4 * q + 0], sinv2, bb.x);
-                acc[t][4 * q + 1] = v.y + fmaf(acc[t][4 * q + 1], sinv2, bb.y);
-                acc[t][4 * q + 2] = v.z + fmaf(acc[t][4 * q + 2], sinv2, bb.z);
-                acc[t][4 * q + 3] = v.w + fmaf(acc[t][4 * q + 3], sinv2, bb.w);
-                sum += (acc[t][4 * q + 0] + acc[t][4 * q + 1]) + (acc[t][4 * q + 2] + acc[t][4 * q + 3]);
+                acc[pt][t][4 * q + 0] = v.x + fmaf(acc[pt][t][4 * q + 0], sinv2, bb.x);
+                acc[pt][t][4 * q + 1] = v.y + fmaf(acc[pt][t][4 * q + 1], sinv2, bb.y);
+                acc[pt][t][4 * q + 2] = v.z + fmaf(acc[pt][t][4 * q + 2], sinv2, bb.z);
+                acc[pt][t][4 * q + 3] = v.w + fmaf(acc[pt][t][4 * q + 3], sinv2, bb.w);
+                sum += (acc[pt][t][4 * q + 0] + acc[pt][t][4 * q + 1]) + (acc[pt][t][4 * q + 2] + acc[pt][t][4 * q + 3]);
             }
         }
         sum += __shfl_xor(sum, 32);
@@ -319,11 +347,11 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
 #pragma unroll
         for (int t = 0; t < C / 32; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float u = acc[t][r] - mean; d = fmaf(u, u, d); }
+            for (int r = 0; r < 16; ++r) { const float u = acc[pt][t][r] - mean; d = fmaf(u, u, d); }
         d += __shfl_xor(d, 32);
         const float sc = kSplitLnScale / sqrtf(d * (1.0f / C) + 1e-6f);
-        if (valid) {
-            char* op = ln_out + mrow * (long long)(C * 4) + 8 * hh;
+        if (valid[pt]) {
+            char* op = ln_out + mrow[pt] * (long long)(C * 4) + 8 * hh;
 #pragma unroll
             for (int t = 0; t < C / 32; ++t) {
 #pragma unroll
@@ -332,7 +360,7 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         f32x2 v;
-                        v.x = (acc[t][4 * q + 2 * e] - mean) * sc; v.y = (acc[t][4 * q + 2 * e + 1] - mean) * sc;
+                        v.x = (acc[pt][t][4 * q + 2 * e] - mean) * sc; v.y = (acc[pt][t][4 * q + 2 * e + 1] - mean) * sc;
                         const h2 h = __builtin_convertvector(v, h2);
                         const f32x2 back = __builtin_convertvector(h, f32x2);
                         const h2 l = __builtin_convertvector(v - back, h2);
@@ -345,8 +373,8 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
                 }
             }
         }
-    } else if (valid) {
-        float* xp = x + mrow * C + 4 * hh;
+    } else if (valid[pt]) {
+        float* xp = x + mrow[pt] * C + 4 * hh;
 #pragma unroll
         for (int t = 0; t < C / 32; ++t) {
 #pragma unroll
@@ -354,24 +382,25 @@ __global__ __launch_bounds__(WideCfg<C>::kThreads) void mlp_fused_wide_kernel(
                 const int c = 32 * t + 8 * q;
                 const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
                 float4 v = *reinterpret_cast<const float4*>(xp + c);
-                v.x += fmaf(acc[t][4 * q + 0], sinv2, bb.x);
-                v.y += fmaf(acc[t][4 * q + 1], sinv2, bb.y);
-                v.z += fmaf(acc[t][4 * q + 2], sinv2, bb.z);
-                v.w += fmaf(acc[t][4 * q + 3], sinv2, bb.w);
+                v.x += fmaf(acc[pt][t][4 * q + 0], sinv2, bb.x);
+                v.y += fmaf(acc[pt][t][4 * q + 1], sinv2, bb.y);
+                v.z += fmaf(acc[pt][t][4 * q + 2], sinv2, bb.z);
+                v.w += fmaf(acc[pt][t][4 * q + 3], sinv2, bb.w);
                 *reinterpret_cast<float4*>(xp + c) = v;
             }
         }
     }
+    }
 }
 
-template <int C, bool LNOUT>
+template <int C, int PT, bool LNOUT>
 static int launch_wide_cfg(const BlockW& w, const float* y, float* x, long long M, void* ln_out, hipStream_t s) {
-    using Cfg = WideCfg<C>;
+    using Cfg = WideCfg<C, PT>;
     static_assert(Cfg::kLdsBytes <= kCuLdsBytes, "weight ring does not fit the LDS");
     static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_kernel<C, LNOUT>, kCuLdsBytes));
+    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_kernel<C, PT, LNOUT>, kCuLdsBytes));
     const long long blocks = (M + Cfg::kPix - 1) / Cfg::kPix;
-    mlp_fused_wide_kernel<C, LNOUT><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s>>>(
+    mlp_fused_wide_kernel<C, PT, LNOUT><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s>>>(
         y, x, reinterpret_cast<const char*>(w.wstream_s), w.b1, w.b2, M, 1.0f / (kSplitLnScale * w.w1s_scale),
         1.0f / (w.hid_scale * w.w2s_scale), w.hid_scale, reinterpret_cast<char*>(ln_out));
     ACX_HIP(hipGetLastError());
@@ -384,8 +413,8 @@ int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, fl
                           void* ln_out) {
     if (!w.wstream_s) ACX_FAIL(ACX_ERR_STATE, "wide fused MLP: the weight stream was not packed for C=%d", C);
     ProfScope ps(c, ACX_K_MLP_FUSED, s);
-    if (C == 384) return ln_out ? launch_wide_cfg<384, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<384, false>(w, y, x, M, nullptr, s);
-    if (C == 192) return ln_out ? launch_wide_cfg<192, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<192, false>(w, y, x, M, nullptr, s);
+    if (C == 384) return ln_out ? launch_wide_cfg<384, 1, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<384, 1, false>(w, y, x, M, nullptr, s);
+    if (C == 192) return ln_out ? launch_wide_cfg<192, 1, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<192, 1, false>(w, y, x, M, nullptr, s);
     ACX_FAIL(ACX_ERR_SHAPE, "wide fused MLP: unsupported channel count %d", C);
 }
 

@@ -14,8 +14,14 @@ ProfScope::~ProfScope() {}
 }
 
 int main(int argc, char** argv) {
-    const int C = 384;
-    const long long M = argc > 1 ? atoll(argv[1]) : 64LL * 63 * 14;
+#ifndef WIDE_C
+#define WIDE_C 384
+#endif
+#ifndef WIDE_FN
+#define WIDE_FN launch_mlp_fused_wide
+#endif
+    const int C = WIDE_C;
+    const long long M = argc > 1 ? atoll(argv[1]) : 64LL * 252 * 56 * 96 / C;
     float *y, *x, *b1, *b2; char* w;
     const size_t wbytes = (size_t)2 * (4 * C / 32) * 128 * C;
     hipMalloc(&y, M * C * 4); hipMalloc(&x, M * C * 4); hipMalloc(&b1, 4 * C * 4); hipMalloc(&b2, C * 4); hipMalloc(&w, wbytes);
@@ -38,12 +44,12 @@ int main(int argc, char** argv) {
     acx::BlockW bw;
     bw.wstream_s = reinterpret_cast<uint16_t*>(w); bw.b1 = b1; bw.b2 = b2; bw.w1s_scale = 1.f; bw.w2s_scale = 1.f; bw.hid_scale = 16.f;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) if (acx::launch_mlp_fused_wide(nullptr, bw, C, y, x, M, 0) != 0) return 1;
+    for (int i = 0; i < 5; ++i) if (acx::WIDE_FN(nullptr, bw, C, y, x, M, 0) != 0) return 1;
     hipDeviceSynchronize();
     float best = 1e9f;
     for (int rep = 0; rep < 6; ++rep) {
         hipEventRecord(e0, 0);
-        for (int r = 0; r < 10; ++r) acx::launch_mlp_fused_wide(nullptr, bw, C, y, x, M, 0);
+        for (int r = 0; r < 10; ++r) acx::WIDE_FN(nullptr, bw, C, y, x, M, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms / 10 < best) best = ms / 10;
