@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("ACX_LIB") or os.path.join(_HERE, "libacx.so")     # A
 OK = 0
 MODE_LOGITS, MODE_SCENE, MODE_FRAME = 0, 1, 2
 KERNEL_CLASSES = ("frontend", "stem", "dwconv", "pw1", "pw2", "rowstats", "downsample", "poolhead", "transpose",
-                  "mlp_fused")
+                  "mlp_fused", "mlp_wide")
 MIN_SAMPLES = 7360
 
 _c_int, _c_i64, _c_sz, _vp = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p

@@ -296,12 +296,27 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     // segments 2k-1 (phase 1 of chunk k + second half of GELU(k-1)) and 2k (phase 2 of chunk k-1 + first half of GELU(k));
     // ring slot = segment % 3
     int grp = 1;
-    for (int k = 1; k < n; ++k) {
+    for (int k = 1; k < n - 1; ++k) {
         phase1(std::true_type{}, k, 2 * k - 1, grp);
         grp = grp == 2 ? 0 : grp + 1;
         phase2(std::true_type{}, 2 * k, grp);
         grp = grp == 2 ? 0 : grp + 1;
     }
+    phase1(std::true_type{}, n - 1, 2 * n - 3, grp);
+    grp = grp == 2 ? 0 : grp + 1;
+    // the activations are dead from here on: their registers take the residual x of the tile, requested two segments
+    // (~2 us) before the epilogue needs it
+    float4 xr[PT][C / 8];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const float* xp = x + mrow[pt] * C + 4 * hh;
+#pragma unroll
+        for (int t = 0; t < C / 32; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[pt][4 * t + q] = *reinterpret_cast<const float4*>(xp + 32 * t + 8 * q);
+    }
+    phase2(std::true_type{}, 2 * n - 2, grp);
+    grp = grp == 2 ? 0 : grp + 1;
     ACX_MICRO_RANGE(1, 0, Cfg::kHalf)       // second half of the last chunk's GELU: no phase-1 segment left to ride on
     ACX_PACK_G()
     phase2(std::false_type{}, 2 * n - 1, grp);
@@ -325,7 +340,6 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     if constexpr (LNOUT) {
         // last block of the stage in the full forward: the only reader of the new x is the LayerNorm in front of the
         // downsample conv (convnext.py:230-235): write its S16 operand instead (see mlp_fused_split.hip)
-        const float* xp = x + mrow[pt] * C + 4 * hh;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < C / 32; ++t) {
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             for (int q = 0; q < 4; ++q) {
                 const int c = 32 * t + 8 * q;
                 const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
-                const float4 v = *reinterpret_cast<const float4*>(xp + c);
+                const float4 v = xr[pt][4 * t + q];
                 acc[pt][t][4 * q + 0] = v.x + fmaf(acc[pt][t][4 * q + 0], sinv2, bb.x);
                 acc[pt][t][4 * q + 1] = v.y + fmaf(acc[pt][t][4 * q + 1], sinv2, bb.y);
                 acc[pt][t][4 * q + 2] = v.z + fmaf(acc[pt][t][4 * q + 2], sinv2, bb.z);
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             for (int q = 0; q < 4; ++q) {
                 const int c = 32 * t + 8 * q;
                 const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
-                float4 v = *reinterpret_cast<const float4*>(xp + c);
+                float4 v = xr[pt][4 * t + q];
                 v.x += fmaf(acc[pt][t][4 * q + 0], sinv2, bb.x);
                 v.y += fmaf(acc[pt][t][4 * q + 1], sinv2, bb.y);
                 v.z += fmaf(acc[pt][t][4 * q + 2], sinv2, bb.z);
@@ -412,7 +426,7 @@ bool mlp_fused_wide_supported(int C) { return C == 384 || C == 192; }
 int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
                           void* ln_out) {
     if (!w.wstream_s) ACX_FAIL(ACX_ERR_STATE, "wide fused MLP: the weight stream was not packed for C=%d", C);
-    ProfScope ps(c, ACX_K_MLP_FUSED, s);
+    ProfScope ps(c, ACX_K_MLP_WIDE, s);
     if (C == 384) return ln_out ? launch_wide_cfg<384, 1, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<384, 1, false>(w, y, x, M, nullptr, s);
     if (C == 192) return ln_out ? launch_wide_cfg<192, 1, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<192, 1, false>(w, y, x, M, nullptr, s);
     ACX_FAIL(ACX_ERR_SHAPE, "wide fused MLP: unsupported channel count %d", C);

@@ -56,6 +56,9 @@ DIMS, DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
 
 
 FUSED_STAGES = (0, 1) if os.environ.get("ACX_DISABLE_FUSED_MLP", "0") != "1" else ()
+# fp32_split: stage 0 runs mlp_fused_split_kernel<96> (class mlp_fused), stages 1-2 mlp_fused_wide_kernel (class mlp_wide),
+# stage 3 the LayerNorm pass + two gemm_split_kernel launches per block
+SPLIT_FUSED_STAGES, SPLIT_WIDE_STAGES = ((0,), (1, 2)) if FUSED_STAGES else ((), ())
 
 
 def algorithmic_work(B, L, precision="fp32"):
@@ -78,9 +81,10 @@ def algorithmic_work(B, L, precision="fp32"):
         n = DEPTHS[s]
         work["dwconv"][0] += n * 2.0 * 49 * pix[s] * C
         work["dwconv"][1] += n * 2.0 * pix[s] * C * 4                      # read x, write y
-        if precision == "fp32_split" and s in FUSED_STAGES:
-            work["mlp_fused"][0] += n * 4.0 * pix[s] * C * 4 * C
-            work["mlp_fused"][1] += n * 3.0 * pix[s] * C * 4                   # y in, x in, x out
+        if precision == "fp32_split" and (s in SPLIT_FUSED_STAGES or s in SPLIT_WIDE_STAGES):
+            k = "mlp_fused" if s in SPLIT_FUSED_STAGES else "mlp_wide"
+            work[k][0] += n * 4.0 * pix[s] * C * 4 * C
+            work[k][1] += n * 3.0 * pix[s] * C * 4                             # y in, x in, x out
         elif precision == "fp32_split":
             work["rowstats"][1] += n * 2.0 * pix[s] * C * 4                    # LayerNorm -> S16 rows, in place
             work["pw1"][0] += n * 2.0 * pix[s] * C * 4 * C
@@ -107,7 +111,9 @@ def algorithmic_work(B, L, precision="fp32"):
             work["downsample"][0] += 2.0 * pix[s] * 4 * DIMS[s - 1] * C
             esz = 2 if precision == "bf16" else 4
             work["downsample"][1] += pix[s - 1] * DIMS[s - 1] * esz + pix[s] * C * 4
-            work["rowstats"][1] += pix[s - 1] * DIMS[s - 1] * (4 + (esz if precision != "fp32" else 0))
+            if not (precision == "fp32_split" and ((s - 1) in SPLIT_FUSED_STAGES or (s - 1) in SPLIT_WIDE_STAGES)):
+                # (in fp32_split the last fused block of the previous stage writes the normalised rows itself)
+                work["rowstats"][1] += pix[s - 1] * DIMS[s - 1] * (4 + (esz if precision != "fp32" else 0))
     work["poolhead"] = [2.0 * B * 768 * 527, pix[3] * 768 * 4]
     return work
 
@@ -353,7 +359,8 @@ def main():
         gemm_name = {"fp32": "gemm_f32_kernel", "bf16": "gemm_bf16_kernel", "fp32_split": "gemm_split_kernel"}[args.precision]
         fused_name = {"fp32": "mlp_fused_kernel", "bf16": "mlp_fused_bf16_kernel", "fp32_split": "mlp_fused_split_kernel"}[args.precision]
         groups = {gemm_name + " (pwconv1+GELU and pwconv2+residual launches, two-GEMM stages)": ("pw1", "pw2"),
-                  fused_name + " (LN+pwconv1+GELU+pwconv2+residual in one launch)": ("mlp_fused",)}
+                  fused_name + " (LN+pwconv1+GELU+pwconv2+residual in one launch)": ("mlp_fused",),
+                  "mlp_fused_wide_kernel (LN+pwconv1+GELU+pwconv2+residual in one launch, stages 1-2)": ("mlp_wide",)}
         merged = {}
         for name, ks in groups.items():
             ks = [k for k in ks if k in kernels]

@@ -70,7 +70,7 @@ enum acx_precision {
 /* kernel classes for acx_profile_read() */
 enum acx_kernel_class {
     ACX_K_FRONTEND = 0, ACX_K_STEM, ACX_K_DWCONV, ACX_K_PW1, ACX_K_PW2, ACX_K_ROWSTATS,
-    ACX_K_DOWNSAMPLE, ACX_K_POOLHEAD, ACX_K_TRANSPOSE, ACX_K_MLP_FUSED, ACX_K_COUNT
+    ACX_K_DOWNSAMPLE, ACX_K_POOLHEAD, ACX_K_TRANSPOSE, ACX_K_MLP_FUSED, ACX_K_MLP_WIDE, ACX_K_COUNT
 };
 
 #define ACX_MIN_SAMPLES 7360  /* shortest clip the reference accepts (last 2x2 downsample needs H>=2) */

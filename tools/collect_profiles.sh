@@ -3,7 +3,7 @@
 set -x
 # usage: collect_profiles.sh [precision]   (fp32_split | fp32 | bf16)
 PREC=${1:-fp32_split}
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$PREC; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$PREC; rm -rf $O; mkdir -p $O
 cd $R && python bench.py --precision $PREC --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --precision $PREC --steps 20 --warmup 3 --no-cpu-baseline --no-profile > $O/stats.log 2>&1

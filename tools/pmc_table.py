@@ -17,7 +17,7 @@ def load(d):
     return rows[idx[-1]:]           # the last forward only
 
 def cls(name):
-    for key, c in (("logmel", "frontend"), ("stem_kernel", "stem"), ("dwconv7", "dwconv"), ("mlp_fused", "mlp_fused"),
+    for key, c in (("logmel", "frontend"), ("stem_kernel", "stem"), ("dwconv7", "dwconv"), ("mlp_fused_wide", "mlp_wide"), ("mlp_fused", "mlp_fused"),
                    ("rowstats", "rowstats"), ("pool_head", "poolhead"), ("nhwc_to_nchw", "transpose")):
         if key in name:
             return c
