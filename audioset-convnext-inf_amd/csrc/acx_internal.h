@@ -88,6 +88,7 @@ struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layou
     uint16_t* w1s = nullptr; // split mode: folded pwconv1 in S16 form (gemm_split.hip), scaled by w1s_scale
     uint16_t* w2s = nullptr; // split mode: gamma * pwconv2 in S16 form, scaled by w2s_scale
     uint16_t* wpack_s = nullptr; // split mode, C = 96/192: chunk-major [W1c | W2c] S16 image (mlp_fused_split.hip)
+    uint16_t* wstream_b = nullptr; // bf16 mode: the same segment stream in bf16, chunks of 64 hidden units (mlp_fused_wide_bf16.hip)
     uint16_t* wstream_s = nullptr; // split mode, C = 384: segment stream in consumption order, LDS image order (mlp_fused_wide.hip)
     float w1s_scale = 1.f, w2s_scale = 1.f;
     float hid_scale = 1.f;   // split mode: power-of-two scale of the S16 hidden activation (GELU output)
@@ -219,6 +220,12 @@ int launch_mlp_fused_split(acx_ctx* c, const BlockW& w, int C, const float* y, f
 bool mlp_fused_wide_supported(int C);
 int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
                           void* ln_out = nullptr);
+// bf16 arithmetic (mlp_fused_wide_bf16.hip): the fused block MLP for C = 96 / 192 / 384; ln_out (with row stride ld_out
+// bf16 elements) receives LayerNorm(x_new) as bf16 rows INSTEAD of x when non-null
+bool mlp_fused_wide_bf16_supported(int C);
+int mlp_fused_wide_bf16_swz(int C, int row);
+int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
+                               void* ln_out = nullptr, int ld_out = 0);
 int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
                      hipStream_t s);
 int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, int W, int C, hipStream_t s);

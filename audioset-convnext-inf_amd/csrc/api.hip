@@ -310,6 +310,37 @@ static int finalize_impl(acx_ctx* c) {
             if (c->precision == ACX_PREC_BF16) {
                 ACX_TRY(upload(c, bf16_rows(f1, 4 * C, 1, C, pad64(C)), &bw.w1h));
                 ACX_TRY(upload(c, bf16_rows(f2, C, 1, 4 * C, 4 * C), &bw.w2h));
+                if (c->use_fused_mlp && mlp_fused_wide_bf16_supported(C)) {
+                    // mlp_fused_wide_bf16.hip: one stream of 128 C-byte segments in consumption order
+                    //   W1(0) W1(1) W2(0) W1(2) W2(1) ... W1(n-1) W2(n-2) W2(n-1),   n = 4C/64 chunks of 64 hidden units,
+                    // each already in LDS image order.
+                    const int nch = 4 * C / 64;
+                    const size_t seg = (size_t)64 * C;                   // uint16 elements per segment
+                    std::vector<uint16_t> st((size_t)2 * nch * seg);
+                    for (int k = 0; k < nch; ++k) {
+                        // W1 image: row r = hidden unit 64k + r (2 C bytes = C/8 chunks of 8 channels), chunk p at p ^ swz(r)
+                        uint16_t* w1img = st.data() + (size_t)(k == 0 ? 0 : 2 * k - 1) * seg;
+                        for (int r = 0; r < 64; ++r)
+                            for (int p = 0; p < C / 8; ++p) {
+                                const int pos = p ^ mlp_fused_wide_bf16_swz(C, r);
+                                for (int e = 0; e < 8; ++e)
+                                    w1img[(size_t)r * C + (size_t)pos * 8 + e] = to_bf16(f1[(size_t)(64 * k + r) * C + 8 * p + e]);
+                            }
+                        // W2 image: row = out channel (128 B = 8 chunks); chunk b = 2 s' + h (s' = k-step 0..3) holds hidden
+                        // units 64k + 32(s' >> 1) + 16(s' & 1) + 4h + 8(jj >> 2) + (jj & 3), at position b ^ ((ch >> 1) & 7)
+                        uint16_t* w2img = st.data() + (size_t)(k == nch - 1 ? 2 * nch - 1 : 2 * k + 2) * seg;
+                        for (int ch = 0; ch < C; ++ch)
+                            for (int b = 0; b < 8; ++b) {
+                                const int sp = b >> 1, h = b & 1;
+                                const int pos = b ^ ((ch >> 1) & 7);
+                                for (int jj = 0; jj < 8; ++jj) {
+                                    const int u = 64 * k + 32 * (sp >> 1) + 16 * (sp & 1) + 4 * h + 8 * (jj >> 2) + (jj & 3);
+                                    w2img[(size_t)ch * 64 + (size_t)pos * 8 + jj] = to_bf16(f2[(size_t)ch * 4 * C + u]);
+                                }
+                            }
+                    }
+                    ACX_TRY(upload(c, st, &bw.wstream_b));
+                }
             }
             if (c->precision == ACX_PREC_F32_SPLIT) {
                 bw.w1s_scale = s16_scale(f1);
@@ -471,6 +502,7 @@ static int run_mlp_split(acx_ctx* c, const BlockW& bw, int C, float* y, float* x
 // True when the last block of stage s can hand the downsample conv its LayerNorm'ed S16 operand directly
 // (fused split MLP kernel, LNOUT epilogue): x of that stage is then NOT updated by its last block.
 static bool block_can_emit_ln(const acx_ctx* c, int s) {
+    if (s < 3 && c->precision == ACX_PREC_BF16 && c->use_fused_mlp && mlp_fused_wide_bf16_supported(kDims[s])) return true;
     return s < 3 && c->precision == ACX_PREC_F32_SPLIT && c->use_fused_mlp &&
            (mlp_fused_supported(kDims[s]) || mlp_fused_wide_supported(kDims[s]));
 }
@@ -489,6 +521,8 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     }
     if (c->precision == ACX_PREC_BF16) {
         ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
+        if (c->use_fused_mlp && bw.wstream_b) return launch_mlp_fused_wide_bf16(c, bw, C, y, x, M, st, ln_out, pad64(C));
+        if (ln_out) ACX_FAIL(ACX_ERR_STATE, "run_block: LayerNorm output requested from a two-GEMM stage");
         return run_mlp_bf16(c, bw, C, y, x, hidden, M, st);
     }
     if (c->use_fused_mlp && mlp_fused_supported(C)) {
@@ -522,7 +556,7 @@ static int run_downsample(acx_ctx* c, int i, const float* x, float* out, float* 
     }
     if (c->precision == ACX_PREC_BF16) {
         const int Cp = pad64(Ci);
-        ACX_TRY(launch_layernorm_rows_bf16(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
+        if (!have_ln) ACX_TRY(launch_layernorm_rows_bf16(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
         GemmBf16Args g{};
         g.A = xnorm; g.Wt = c->down[i].wh; g.bias = c->down[i].b; g.out = out;
         g.gather = 1; g.H = H; g.W = Wd; g.Cp = Cp; g.Ho = H / 2; g.Wo = Wd / 2;

@@ -4,7 +4,7 @@
 //   A operands are bf16 in HBM: the fp32 LayerNorm pass writes its normalised rows as bf16 (ln_rows_bf16 in
 //   dwconv.hip), pwconv1's epilogue writes the hidden activation as bf16.  Weights are rounded to bf16 once
 //   at acx_finalize (K padded to a multiple of 64).
-// Same structure as gemm.hip: 128 x BN tiles, 128-B LDS rows (= 64 bf16 of K), both operands by LDS-DMA with
+// Same structure as gemm.hip, as 8-wave CU-exclusive workgroups (acx_internal.h): 256 x BN tiles, 128-B LDS rows (= 64 bf16 of K), both operands by LDS-DMA with
 // the XOR swizzle on the source address, fragments double-buffered in registers, one barrier per k-tile.  A
 // fragment read is still one ds_read_b128: lane half h takes chunk 2g+h of its row = k 16g+8h .. +7, exactly
 // the A/B lane map of the 32x32x16 instruction, so one MFMA per (tile, k-group) replaces four fp32 ones.
@@ -45,11 +45,13 @@ __device__ __forceinline__ void lds_dma16_b(const __bf16* gsrc, char* lds_wave_b
 
 // EPI: 0 bias -> fp32, 1 bias + GELU -> bf16, 2 bias + residual -> fp32
 template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p) {
     constexpr int TM = kBM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
+    constexpr int NW = WM * WN;                                            // 8 waves: one CU-exclusive workgroup per CU
     constexpr int A_TILE = kBM * kBfRowBytes, B_TILE = BN * kBfRowBytes;
-    constexpr int A_DMA = kBM / 32, B_DMA = BN / 32;
+    constexpr int A_DMA = kBM / (8 * NW), B_DMA = BN / (8 * NW);           // 1-KB pieces per wave per tile
+    static_assert(NW == 8 && A_DMA * 8 * NW == kBM && B_DMA * 8 * NW == BN, "8-wave tiles of 8-row pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
     char* Bs = smem + 2 * A_TILE;
@@ -60,9 +62,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     // CU-exclusive (acx_internal.h): dense 16-bit MFMA next to foreign packed-FP32 work is the same hazard as in the split
-    // kernels (found by the bs = 64 two-stream bf16 test).  One 4-wave workgroup per CU, 512 registers per lane claimed.
+    // kernels (found by the bs = 64 two-stream bf16 test).  One 8-wave workgroup per CU, 256 registers per lane claimed.
     ACX_CLAIM_VGPR(255);
-    ACX_CLAIM_AGPR(255);
     long long lid = blockIdx.x;
     {
         const long long nwg = gridDim.x, per = (nwg + 7) >> 3, full = nwg - (per - 1) * 8;
@@ -243,16 +244,16 @@ static int launch_bf_cfg(const GemmBfParams& p0, hipStream_t s) {
     constexpr size_t lds = kCuLdsBytes;          // all of it: CU-exclusive
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER>, lds));
-    gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(p);
+    gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(64 * WM * WN), lds, s>>>(p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
 
 template <int EPI, int GATHER>
 static int launch_bf_bn(const GemmBfParams& p, hipStream_t s) {
-    if (p.N % 128 == 0) return launch_bf_cfg<128, 128, 2, 2, EPI, GATHER>(p, s);
-    if (p.N % 96 == 0) return launch_bf_cfg<128, 96, 4, 1, EPI, GATHER>(p, s);
-    ACX_FAIL(ACX_ERR_SHAPE, "gemm_bf16: N=%d is not a multiple of 96 or 128", p.N);
+    if (p.N % 192 == 0) return launch_bf_cfg<256, 192, 4, 2, EPI, GATHER>(p, s);      // every N of the model
+    if (p.N % 128 == 0) return launch_bf_cfg<256, 128, 4, 2, EPI, GATHER>(p, s);
+    ACX_FAIL(ACX_ERR_SHAPE, "gemm_bf16: N=%d is not a multiple of 192 or 128", p.N);
 }
 
 int launch_gemm_bf16(acx_ctx* c, const GemmBf16Args& a, hipStream_t s) {

@@ -1,0 +1,386 @@
+// K4fb -- the fused block MLP (LayerNorm -> pwconv1 -> GELU -> pwconv2 -> gamma -> + residual, convnext.py:77-86) in the
+// `bf16` arithmetic of BASELINE configs[2] ("bf16 with fp32 LayerNorm"): bf16 MFMA operands (LayerNorm output, weights,
+// hidden activation), fp32 accumulation, fp32 LayerNorm statistics, GELU and residual stream.  The dataflow, the weight
+// stream through a 3-slot LDS ring, the one-wave-per-SIMD schedule and the CU-exclusive launch are those of
+// mlp_fused_wide.hip; what changes with ONE v_mfma_f32_32x32x16_bf16 per product instead of three fp16 ones:
+//   * a chunk is 64 hidden units (two 32 x 32 pre-activation tiles): a segment -- the [64 x C] W1 image or the [C x 64]
+//     W2 image of a chunk, 128 C bytes -- then carries as many MFMAs (C/8 per pixel tile) relative to its fixed costs
+//     (LDS-DMA issues, barrier) as half a split segment does, instead of a third;
+//   * the GELU is the 7 scalar micro-steps of split_math.h plus one bf16 pack (no lo half): 128 micro-steps per chunk and
+//     pixel tile, half of them dealt over the MFMAs of each of the chunk's two segments.  At one MFMA per product the
+//     vector work outweighs the matrix work for C <= 192: those stages are bound by the GELU's vector issue.
+// Rounding points are those of the un-fused bf16 path (and of tests/test_gpu_bf16.py's emulation): LayerNorm output and
+// GELU output rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32), weights rounded once at acx_finalize.
+#include <type_traits>
+
+#include "acx_internal.h"
+#include "split_math.h"
+
+namespace acx {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int C, int PT>
+struct WideBfCfg {
+    static constexpr int kWaves = 4;
+    static constexpr int kThreads = kWaves * 64;
+    static constexpr int kPix = kWaves * 32 * PT;
+    static constexpr int kChunks = 4 * C / 64;              // n: chunks of 64 hidden units
+    static constexpr int kSegs = 2 * kChunks;
+    static constexpr int kSegBytes = 128 * C;               // [64][C] or [C][64] bf16
+    static constexpr int kPieces = kSegBytes / 1024 / kWaves;
+    static constexpr int kSteps = C / 16;                   // k-steps of phase 1
+    static constexpr int kTiles = C / 32;                   // out tiles of phase 2
+    static constexpr int kUnits = 2 * kSteps;               // fragment reads of a segment: (k-step, X tile) or (out tile, k-step): 4 kTiles = 2 kSteps
+    static constexpr int kMfmas = kUnits * PT;              // MFMAs per segment
+    static constexpr int kHalf = 64 * PT;                   // GELU micro-steps a segment carries
+    static constexpr size_t kLdsBytes = 3 * (size_t)kSegBytes + 4 * C * 4;
+    static_assert(C % 32 == 0 && kUnits % kPieces == 0, "unit / piece bookkeeping");
+    // W1 rows are 2 C bytes = C/8 chunks of 16 B: the XOR that spreads 16 consecutive rows over the LDS banks
+    static constexpr int kSwzBits = (C % 128 == 0) ? 4 : ((C % 64 == 0) ? 3 : 2);
+    __host__ __device__ static int swz1(int row) { return kSwzBits == 4 ? (row & 15) : (kSwzBits == 3 ? ((row >> 1) & 7) : ((row >> 2) & 3)); }
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    f32x2 v; v.x = a; v.y = b;
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(unsigned, h);
+}
+
+template <int C, int PT, bool LNOUT>
+__global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
+    const float* __restrict__ y, float* __restrict__ x, const char* __restrict__ wstream /*[2n][128 C bytes]*/,
+    const float* __restrict__ b1, const float* __restrict__ b2, long long M, int ld_out,
+    __bf16* __restrict__ ln_out /* LNOUT: (M, ld_out) bf16 rows of LayerNorm(x_new), written INSTEAD of x */) {
+    using Cfg = WideBfCfg<C, PT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* b1s = reinterpret_cast<float*>(smem + 3 * Cfg::kSegBytes);   // [4C]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    ACX_CLAIM_VGPR(255);          // CU-exclusive: one wave per SIMD holds the SIMD's whole register file
+    ACX_CLAIM_AGPR(255);
+    long long mrow[PT];
+    bool valid[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        mrow[pt] = (long long)blockIdx.x * Cfg::kPix + (wave * PT + pt) * 32 + l31;
+        valid[pt] = mrow[pt] < M;
+        if (!valid[pt]) mrow[pt] = M - 1;
+    }
+
+    constexpr int n = Cfg::kChunks;
+    const int dma_lane = (wave * Cfg::kPieces) * 1024 + lane * 16;
+#define ACX_WDMA(seg_, piece_, grp_)                                                                             \
+        __builtin_amdgcn_global_load_lds(                                                                        \
+            (const __attribute__((address_space(1))) void*)(wstream + (long long)(seg_) * Cfg::kSegBytes + dma_lane + (piece_) * 1024), \
+            (__attribute__((address_space(3))) void*)(smem + (grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_)) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(0, p, 0)
+#pragma unroll
+    for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(1, p, 1)
+    for (int i = tid; i < 4 * C; i += Cfg::kThreads) b1s[i] = b1[i];
+
+    // ---- this wave's activations: lane (px = l31, half hh) holds channels 16s + 8hh .. +7 as 8 bf16, s = 0..C/16-1 ----
+    f32x4 act[PT][Cfg::kSteps];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        float a[C / 2];
+        const float* yp = y + mrow[pt] * C + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < Cfg::kSteps; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(yp + 16 * s);
+            const float4 v1 = *reinterpret_cast<const float4*>(yp + 16 * s + 4);
+            a[8 * s + 0] = v0.x; a[8 * s + 1] = v0.y; a[8 * s + 2] = v0.z; a[8 * s + 3] = v0.w;
+            a[8 * s + 4] = v1.x; a[8 * s + 5] = v1.y; a[8 * s + 6] = v1.z; a[8 * s + 7] = v1.w;
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) sum += a[i];
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / C);
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) { const float t = a[i] - mean; d = fmaf(t, t, d); }
+        d += __shfl_xor(d, 32);
+        const float rstd = 1.0f / sqrtf(d * (1.0f / C) + 1e-6f);
+#pragma unroll
+        for (int s = 0; s < Cfg::kSteps; ++s) {
+            unsigned u4[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) u4[p] = pack_bf16((a[8 * s + 2 * p] - mean) * rstd, (a[8 * s + 2 * p + 1] - mean) * rstd);
+            act[pt][s] = __builtin_bit_cast(f32x4, uint4{u4[0], u4[1], u4[2], u4[3]});
+        }
+    }
+
+    f32x16 acc[PT][Cfg::kTiles];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pt][t][r] = 0.f;
+
+    // fragment addresses inside a segment (without the ring offset):
+    //   W1 image: row = hidden unit of the chunk (0..63), 2 C bytes = C/8 chunks of 16 B; X tile j uses rows 32 j + l31; the
+    //             fragment of k-step s is chunk p = 2 s + hh at position p ^ swz1(row) (swz1(32 j + l31) == swz1(l31))
+    //   W2 image: row = out channel (128 B = 8 chunks), tile t rows 32 t + l31, chunk 2 s' + hh at position ^ ((l31 >> 1) & 7)
+    constexpr int kVar1 = 1 << (Cfg::kSwzBits - 1);          // k-steps whose chunk index differs in the XORed low bits
+    int w1off[kVar1], w2off[4];
+#pragma unroll
+    for (int q = 0; q < kVar1; ++q) w1off[q] = l31 * (2 * C) + (((2 * q + hh) ^ Cfg::swz1(l31)) << 4);
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) w2off[sp] = l31 * 128 + (((2 * sp + hh) ^ ((l31 >> 1) & 7)) << 4);
+    GeluConsts gk;                // X holds the pre-activation itself (no operand scales in this arithmetic)
+    gk.ps = 0.3275911f * 0.70710678f;
+    gk.cq = 0.84932180f;
+    gk.ca = -0.5f;
+    gk.cb = 1.0f;
+
+#define ACX_B8(v_) __builtin_bit_cast(bf16x8, v_)
+#define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
+    // phase-1 unit u = (k-step s = u >> 1, X tile j = u & 1)
+#define ACX_W1_RD(base_, u_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) & 1) * (32 * 2 * C) + (((u_) >> 1) / kVar1) * (kVar1 * 32) + w1off[((u_) >> 1) % kVar1]))
+    // MFMA number m_ of a segment is followed (behind a scheduling fence) by its share of the kHalf GELU micro-steps
+#define ACX_AFTER_MFMA(HV_, half_, m_)                                                                          \
+        ACX_FENCE if constexpr (HV_) { ACX_MICRO_RANGE(half_, Cfg::kHalf * (m_) / Cfg::kMfmas, Cfg::kHalf * ((m_) + 1) / Cfg::kMfmas) } ACX_FENCE
+#define ACX_P1_MFMA(u_, f_)                                                                                     \
+        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
+            Xn[pt_][(u_) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ACX_B8(f_), ACX_B8(act[pt_][(u_) >> 1]), Xn[pt_][(u_) & 1], 0, 0, 0); \
+            ACX_AFTER_MFMA(HV, 1, (u_) * PT + pt_) }
+    // phase-2 unit u = (out tile t = u >> 2, k-step s' = u & 3)
+#define ACX_W2_RD(base_, u_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) >> 2) * 4096 + w2off[(u_) & 3]))
+#define ACX_P2_MFMA(u_, f_)                                                                                     \
+        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
+            acc[pt_][(u_) >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ACX_B8(f_), ACX_B8(g[pt_][(u_) & 3]), acc[pt_][(u_) >> 2], 0, 0, 0); \
+            ACX_AFTER_MFMA(HV, 0, (u_) * PT + pt_) }
+    // micro-steps [from, to) of the kHalf that segment half half_ carries: step sg_ belongs to pixel tile sg_ / 64; half h
+    // is X tile j = h of the chunk: 8 register pairs x 8 steps (7 of the GELU, 1 bf16 pack) turn Xv[.][j] into un[.][j]
+#define ACX_MICRO_RANGE(half_, from_, to_)                                                                      \
+        _Pragma("unroll") for (int sg_ = (from_); sg_ < (to_); ++sg_) {                                         \
+            const int mt_ = sg_ / 64, pr_ = (sg_ % 64) / 8, st_ = sg_ % 8;                                      \
+            unsigned dummy_;                                                                                    \
+            if (st_ == 0) { gs.ax = Xv[mt_][half_][2 * pr_]; gs.ay = Xv[mt_][half_][2 * pr_ + 1]; gelu_micro<0>(gs, gk, dummy_, dummy_); } \
+            else if (st_ == 1) gelu_micro<1>(gs, gk, dummy_, dummy_);                                           \
+            else if (st_ == 2) gelu_micro<2>(gs, gk, dummy_, dummy_);                                           \
+            else if (st_ == 3) gelu_micro<3>(gs, gk, dummy_, dummy_);                                           \
+            else if (st_ == 4) gelu_micro<4>(gs, gk, dummy_, dummy_);                                           \
+            else if (st_ == 5) gelu_micro<5>(gs, gk, dummy_, dummy_);                                           \
+            else if (st_ == 6) gelu_micro<6>(gs, gk, dummy_, dummy_);                                           \
+            else un[mt_][half_][pr_] = pack_bf16(gs.gx, gs.gy);                                                 \
+        }
+#define ACX_TOUCH1(f_) { asm volatile("" :: "v"(f_)); }
+    // Xn[.][j] starts from the bias of hidden units 64 k + 32 j + (lane layout of a 32 x 32 accumulator)
+#define ACX_BIAS_INIT(k_)                                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 64 * (k_) + 32 * j_ + 8 * q + 4 * hh);       \
+            _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                              \
+                Xn[pt_][j_][4 * q + 0] = bq[0]; Xn[pt_][j_][4 * q + 1] = bq[1]; Xn[pt_][j_][4 * q + 2] = bq[2]; Xn[pt_][j_][4 * q + 3] = bq[3]; } \
+        }
+    // G of the chunk: k-step s' = 2 j + (pair >> 2) of phase 2 takes pairs 4 (s' & 1) .. + 3 of X tile j
+#define ACX_PACK_G()                                                                                            \
+        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_)                                                    \
+        _Pragma("unroll") for (int sp_ = 0; sp_ < 4; ++sp_)                                                     \
+            g[pt_][sp_] = __builtin_bit_cast(f32x4, uint4{un[pt_][sp_ >> 1][4 * (sp_ & 1) + 0], un[pt_][sp_ >> 1][4 * (sp_ & 1) + 1], \
+                                                          un[pt_][sp_ >> 1][4 * (sp_ & 1) + 2], un[pt_][sp_ >> 1][4 * (sp_ & 1) + 3]});
+#define ACX_SEG_END(issued_)                                                                                    \
+        ACX_FENCE                                                                                               \
+        if (issued_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::kPieces) : "memory");                       \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        ACX_FENCE
+
+    f32x16 Xn[PT][2], Xv[PT][2];  // Xn: pre-activation tiles being accumulated by phase 1; Xv: the previous chunk's, input of the GELU
+    f32x4 g[PT][4];               // G(k - 1): B operand of phase 2, four k-steps of 8 bf16
+    unsigned un[PT][2][8];        // G(k) under construction
+    constexpr int kDmaStride = Cfg::kUnits / Cfg::kPieces;
+    GeluState gs;
+
+    auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
+        constexpr bool HV = decltype(with_gelu)::value;     // second half (X tile 1) of the GELU of Xv rides on this segment's MFMAs
+        const char* base = smem + grp_ * Cfg::kSegBytes;
+        const bool dma = seg_ + 2 < Cfg::kSegs;
+        const int g2 = (grp_ + 2) % 3;
+        ACX_BIAS_INIT(k_)
+        f32x4 f0 = ACX_W1_RD(base, 0), f1;
+#pragma unroll
+        for (int u = 0; u < Cfg::kUnits; u += 2) {
+            f1 = ACX_W1_RD(base, u + 1);
+            ACX_FENCE
+            ACX_P1_MFMA(u, f0)
+            if (u % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, u / kDmaStride, g2) }
+            ACX_FENCE
+            ACX_TOUCH1(f1)
+            if (u + 2 < Cfg::kUnits) f0 = ACX_W1_RD(base, u + 2);
+            ACX_FENCE
+            ACX_P1_MFMA(u + 1, f1)
+            if ((u + 1) % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (u + 1) / kDmaStride, g2) }
+            ACX_FENCE
+            if (u + 2 < Cfg::kUnits) ACX_TOUCH1(f0)
+        }
+        if constexpr (HV) { ACX_PACK_G() }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) { Xv[pt][0] = Xn[pt][0]; Xv[pt][1] = Xn[pt][1]; }
+        ACX_SEG_END(dma)
+    };
+    auto phase2 = [&](auto with_gelu, const int seg_, const int grp_) __attribute__((always_inline)) {
+        constexpr bool HV = decltype(with_gelu)::value;     // first half (X tile 0) of the GELU of Xv (the NEXT chunk) rides here
+        const char* base = smem + grp_ * Cfg::kSegBytes;
+        const bool dma = seg_ + 2 < Cfg::kSegs;
+        const int g2 = (grp_ + 2) % 3;
+        f32x4 f0 = ACX_W2_RD(base, 0), f1;
+#pragma unroll
+        for (int u = 0; u < Cfg::kUnits; u += 2) {
+            f1 = ACX_W2_RD(base, u + 1);
+            ACX_FENCE
+            ACX_P2_MFMA(u, f0)
+            if (u % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, u / kDmaStride, g2) }
+            ACX_FENCE
+            ACX_TOUCH1(f1)
+            if (u + 2 < Cfg::kUnits) f0 = ACX_W2_RD(base, u + 2);
+            ACX_FENCE
+            ACX_P2_MFMA(u + 1, f1)
+            if ((u + 1) % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (u + 1) / kDmaStride, g2) }
+            ACX_FENCE
+            if (u + 2 < Cfg::kUnits) ACX_TOUCH1(f0)
+        }
+        ACX_SEG_END(dma)
+    };
+
+    __syncthreads();      // segments 0 and 1 landed (hipcc drains the LDS-DMA before the barrier); b1s visible
+    phase1(std::false_type{}, 0, 0, 0);
+    ACX_MICRO_RANGE(0, 0, Cfg::kHalf)
+    int grp = 1;
+    for (int k = 1; k < n - 1; ++k) {
+        phase1(std::true_type{}, k, 2 * k - 1, grp);
+        grp = grp == 2 ? 0 : grp + 1;
+        phase2(std::true_type{}, 2 * k, grp);
+        grp = grp == 2 ? 0 : grp + 1;
+    }
+    phase1(std::true_type{}, n - 1, 2 * n - 3, grp);
+    grp = grp == 2 ? 0 : grp + 1;
+    // the activations are dead from here on: their registers take the residual x of the tile
+    float4 xr[PT][C / 8];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const float* xp = x + mrow[pt] * C + 4 * hh;
+#pragma unroll
+        for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[pt][4 * t + q] = *reinterpret_cast<const float4*>(xp + 32 * t + 8 * q);
+    }
+    phase2(std::true_type{}, 2 * n - 2, grp);
+    grp = grp == 2 ? 0 : grp + 1;
+    ACX_MICRO_RANGE(1, 0, Cfg::kHalf)       // second half of the last chunk's GELU: no phase-1 segment left to ride on
+    ACX_PACK_G()
+    phase2(std::false_type{}, 2 * n - 1, grp);
+#undef ACX_WDMA
+#undef ACX_B8
+#undef ACX_FENCE
+#undef ACX_W1_RD
+#undef ACX_AFTER_MFMA
+#undef ACX_P1_MFMA
+#undef ACX_W2_RD
+#undef ACX_P2_MFMA
+#undef ACX_MICRO_RANGE
+#undef ACX_TOUCH1
+#undef ACX_BIAS_INIT
+#undef ACX_PACK_G
+#undef ACX_SEG_END
+
+    // ---- epilogue: lane (px, hh), tile t, q: channels 32t + 8q + 4hh .. +3  ->  x = x + out + b2 ---------
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        if constexpr (LNOUT) {
+            // last block of the stage in the full forward: the only reader of the new x is the LayerNorm in front of the
+            // downsample conv (convnext.py:230-235): write that GEMM's bf16 operand rows instead of x
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bb = *reinterpret_cast<const float4*>(b2 + 32 * t + 8 * q + 4 * hh);
+                    const float4 v = xr[pt][4 * t + q];
+                    acc[pt][t][4 * q + 0] += v.x + bb.x; acc[pt][t][4 * q + 1] += v.y + bb.y;
+                    acc[pt][t][4 * q + 2] += v.z + bb.z; acc[pt][t][4 * q + 3] += v.w + bb.w;
+                    sum += (acc[pt][t][4 * q + 0] + acc[pt][t][4 * q + 1]) + (acc[pt][t][4 * q + 2] + acc[pt][t][4 * q + 3]);
+                }
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / C);
+            float d = 0.f;
+#pragma unroll
+            for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float u = acc[pt][t][r] - mean; d = fmaf(u, u, d); }
+            d += __shfl_xor(d, 32);
+            const float rstd = 1.0f / sqrtf(d * (1.0f / C) + 1e-6f);
+            if (valid[pt]) {
+                __bf16* op = ln_out + mrow[pt] * (long long)ld_out + 4 * hh;
+#pragma unroll
+                for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint2 o;
+                        o.x = pack_bf16((acc[pt][t][4 * q + 0] - mean) * rstd, (acc[pt][t][4 * q + 1] - mean) * rstd);
+                        o.y = pack_bf16((acc[pt][t][4 * q + 2] - mean) * rstd, (acc[pt][t][4 * q + 3] - mean) * rstd);
+                        *reinterpret_cast<uint2*>(op + 32 * t + 8 * q) = o;
+                    }
+                // the row is ld_out = pad64(C) elements long (the GEMM's K is padded with zero weights): zero the padding, or
+                // stale bytes that happen to be NaN would poison the products
+                for (int c = C + 4 * hh; c < ld_out; c += 8)
+                    *reinterpret_cast<uint2*>(ln_out + mrow[pt] * (long long)ld_out + c) = uint2{0u, 0u};
+            }
+        } else if (valid[pt]) {
+            float* xp = x + mrow[pt] * C + 4 * hh;
+#pragma unroll
+            for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 32 * t + 8 * q;
+                    const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
+                    float4 v = xr[pt][4 * t + q];
+                    v.x += acc[pt][t][4 * q + 0] + bb.x;
+                    v.y += acc[pt][t][4 * q + 1] + bb.y;
+                    v.z += acc[pt][t][4 * q + 2] + bb.z;
+                    v.w += acc[pt][t][4 * q + 3] + bb.w;
+                    *reinterpret_cast<float4*>(xp + c) = v;
+                }
+        }
+    }
+}
+
+template <int C, int PT, bool LNOUT>
+static int launch_wide_bf16_cfg(const BlockW& w, const float* y, float* x, long long M, void* ln_out, int ld_out, hipStream_t s) {
+    using Cfg = WideBfCfg<C, PT>;
+    static_assert(Cfg::kLdsBytes <= kCuLdsBytes, "weight ring does not fit the LDS");
+    static DeviceOnce once;
+    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_bf16_kernel<C, PT, LNOUT>, kCuLdsBytes));
+    const long long blocks = (M + Cfg::kPix - 1) / Cfg::kPix;
+    mlp_fused_wide_bf16_kernel<C, PT, LNOUT><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s>>>(
+        y, x, reinterpret_cast<const char*>(w.wstream_b), w.b1, w.b2, M, ld_out, reinterpret_cast<__bf16*>(ln_out));
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
+bool mlp_fused_wide_bf16_supported(int C) { return C == 384 || C == 192 || C == 96; }
+
+// LDS position of 16-byte chunk p of row `row` of a W1 image (acx_finalize packs the stream with it)
+int mlp_fused_wide_bf16_swz(int C, int row) {
+    return C == 384 ? WideBfCfg<384, 1>::swz1(row) : (C == 192 ? WideBfCfg<192, 1>::swz1(row) : WideBfCfg<96, 1>::swz1(row));
+}
+
+int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
+                               void* ln_out, int ld_out) {
+    if (!w.wstream_b) ACX_FAIL(ACX_ERR_STATE, "fused bf16 MLP: the weight stream was not packed for C=%d", C);
+    ProfScope ps(c, ACX_K_MLP_WIDE, s);
+    if (C == 384) return ln_out ? launch_wide_bf16_cfg<384, 1, true>(w, y, x, M, ln_out, ld_out, s) : launch_wide_bf16_cfg<384, 1, false>(w, y, x, M, nullptr, 0, s);
+    if (C == 192) return ln_out ? launch_wide_bf16_cfg<192, 1, true>(w, y, x, M, ln_out, ld_out, s) : launch_wide_bf16_cfg<192, 1, false>(w, y, x, M, nullptr, 0, s);
+    if (C == 96) return ln_out ? launch_wide_bf16_cfg<96, 2, true>(w, y, x, M, ln_out, ld_out, s) : launch_wide_bf16_cfg<96, 2, false>(w, y, x, M, nullptr, 0, s);
+    ACX_FAIL(ACX_ERR_SHAPE, "fused bf16 MLP: unsupported channel count %d", C);
+}
+
+}  // namespace acx
