@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     gk.ps = 0.3275911f * 0.70710678f;
     gk.cq = 0.84932180f;
     gk.ca = -0.5f;
-    gk.cb = 1.0f;
+    gk.cb = 1.0f;             // (gelu_micro<., UNIT = true> does not use them)
 
 #define ACX_B8(v_) __builtin_bit_cast(bf16x8, v_)
 #define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
@@ -163,13 +163,13 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
         _Pragma("unroll") for (int sg_ = (from_); sg_ < (to_); ++sg_) {                                         \
             const int mt_ = sg_ / 64, pr_ = (sg_ % 64) / 8, st_ = sg_ % 8;                                      \
             unsigned dummy_;                                                                                    \
-            if (st_ == 0) { gs.ax = Xv[mt_][half_][2 * pr_]; gs.ay = Xv[mt_][half_][2 * pr_ + 1]; gelu_micro<0>(gs, gk, dummy_, dummy_); } \
-            else if (st_ == 1) gelu_micro<1>(gs, gk, dummy_, dummy_);                                           \
-            else if (st_ == 2) gelu_micro<2>(gs, gk, dummy_, dummy_);                                           \
-            else if (st_ == 3) gelu_micro<3>(gs, gk, dummy_, dummy_);                                           \
-            else if (st_ == 4) gelu_micro<4>(gs, gk, dummy_, dummy_);                                           \
-            else if (st_ == 5) gelu_micro<5>(gs, gk, dummy_, dummy_);                                           \
-            else if (st_ == 6) gelu_micro<6>(gs, gk, dummy_, dummy_);                                           \
+            if (st_ == 0) { gs.ax = Xv[mt_][half_][2 * pr_]; gs.ay = Xv[mt_][half_][2 * pr_ + 1]; gelu_micro<0, true>(gs, gk, dummy_, dummy_); } \
+            else if (st_ == 1) gelu_micro<1, true>(gs, gk, dummy_, dummy_);                                           \
+            else if (st_ == 2) gelu_micro<2, true>(gs, gk, dummy_, dummy_);                                           \
+            else if (st_ == 3) gelu_micro<3, true>(gs, gk, dummy_, dummy_);                                           \
+            else if (st_ == 4) gelu_micro<4, true>(gs, gk, dummy_, dummy_);                                           \
+            else if (st_ == 5) gelu_micro<5, true>(gs, gk, dummy_, dummy_);                                           \
+            else if (st_ == 6) gelu_micro<6, true>(gs, gk, dummy_, dummy_);                                           \
             else un[mt_][half_][pr_] = pack_bf16(gs.gx, gs.gy);                                                 \
         }
 #define ACX_TOUCH1(f_) { asm volatile("" :: "v"(f_)); }
@@ -366,6 +366,241 @@ static int launch_wide_bf16_cfg(const BlockW& w, const float* y, float* x, long 
     return ACX_OK;
 }
 
+// ---- C = 96: weights-stationary variant -------------------------------------------------------------------------------
+// At C = 96 the WHOLE bf16 weight stream (12 segments x 12 KB = 144 KB) fits the LDS.  A persistent workgroup (one per
+// CU, 8 waves) loads it once; after that its waves never synchronise again: each walks its own 32-pixel tiles
+// (LayerNorm -> 6 chunks of [phase 1, GELU, phase 2] -> residual store) at its own pace.  What that buys over the ring
+// kernel above: its workgroups all moved through "load the tile / compute / store the tile" in step, so the HBM phase
+// (3 tensor passes, ~190 us per block at the HBM rate) and the compute phase (~210 us) added up; free-running waves
+// spread over all phases, memory latency hides behind the other waves' matrix and vector work, and the per-segment
+// barrier and LDS-DMA issue are gone.  Same stream layout (api.hip packs one `wstream_b` for both kernels), same
+// arithmetic and rounding points.
+template <bool LNOUT>
+__global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
+    const float* __restrict__ y, float* __restrict__ x, const char* __restrict__ wstream /*[12][12288 B]*/,
+    const float* __restrict__ b1, const float* __restrict__ b2, long long M, int ld_out, __bf16* __restrict__ ln_out) {
+    constexpr int C = 96;
+    using Cfg = WideBfCfg<C, 1>;
+    constexpr int n = Cfg::kChunks;                           // 6 chunks of 64 hidden units
+    constexpr int kStreamBytes = Cfg::kSegs * Cfg::kSegBytes; // 147 456
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* b1s = reinterpret_cast<float*>(smem + kStreamBytes);   // [4C]
+    float* b2s = b1s + 4 * C;                                     // [C]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    ACX_CLAIM_VGPR(255);          // CU-exclusive: 8 waves x 256 registers hold the SIMDs' whole register files
+
+    // the stream into the LDS: 144 pieces of 1 KB, 18 per wave
+#pragma unroll
+    for (int p = 0; p < kStreamBytes / 1024 / 8; ++p) {
+        const int piece = wave * (kStreamBytes / 1024 / 8) + p;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wstream + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, 0, 0);
+    }
+    for (int i = tid; i < 4 * C; i += 512) b1s[i] = b1[i];
+    if (tid < C) b2s[tid] = b2[tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    constexpr int kVar1 = 1 << (Cfg::kSwzBits - 1);
+    int w1off[kVar1], w2off[4];
+#pragma unroll
+    for (int q = 0; q < kVar1; ++q) w1off[q] = l31 * (2 * C) + (((2 * q + hh) ^ Cfg::swz1(l31)) << 4);
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) w2off[sp] = l31 * 128 + (((2 * sp + hh) ^ ((l31 >> 1) & 7)) << 4);
+    GeluConsts gk;
+    gk.ps = 0.3275911f * 0.70710678f;
+    gk.cq = 0.84932180f;
+    gk.ca = -0.5f;
+    gk.cb = 1.0f;             // (gelu_micro<., UNIT = true> does not use them)
+#define ACX_B8(v_) __builtin_bit_cast(bf16x8, v_)
+#define ACX_W1_RD(base_, u_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) & 1) * (32 * 2 * C) + (((u_) >> 1) / kVar1) * (kVar1 * 32) + w1off[((u_) >> 1) % kVar1]))
+#define ACX_W2_RD(base_, u_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) >> 2) * 4096 + w2off[(u_) & 3]))
+
+    const long long ntiles = (M + 31) / 32;
+    const long long tstride = (long long)gridDim.x * 8;
+    // software pipeline over the wave's tiles: the y rows of tile i + 1 are requested before the chunks of tile i start
+    float4 yn[C / 8];
+#define ACX_LOAD_Y(tile_)                                                                                       \
+    {   long long r_ = (tile_) * 32 + l31; if (r_ >= M) r_ = M - 1;                                             \
+        const float* yp_ = y + r_ * C + 8 * hh;                                                                 \
+        _Pragma("unroll") for (int s = 0; s < Cfg::kSteps; ++s) {                                               \
+            yn[2 * s] = *reinterpret_cast<const float4*>(yp_ + 16 * s); yn[2 * s + 1] = *reinterpret_cast<const float4*>(yp_ + 16 * s + 4); } }
+    long long tile = (long long)blockIdx.x * 8 + wave;
+    if (tile < ntiles) ACX_LOAD_Y(tile)
+    for (; tile < ntiles; tile += tstride) {
+        long long mrow = tile * 32 + l31;
+        const bool valid = mrow < M;
+        if (!valid) mrow = M - 1;
+        // ---- LayerNorm of the tile's rows: lane (px = l31, half hh) holds channels 16 s + 8 hh .. + 7 ----
+        f32x4 act[Cfg::kSteps];
+        {
+            float a[C / 2];
+#pragma unroll
+            for (int i = 0; i < C / 8; ++i) { a[4 * i] = yn[i].x; a[4 * i + 1] = yn[i].y; a[4 * i + 2] = yn[i].z; a[4 * i + 3] = yn[i].w; }
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) sum += a[i];
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / C);
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) { const float t = a[i] - mean; d = fmaf(t, t, d); }
+            d += __shfl_xor(d, 32);
+            const float rstd = 1.0f / sqrtf(d * (1.0f / C) + 1e-6f);
+#pragma unroll
+            for (int s = 0; s < Cfg::kSteps; ++s) {
+                unsigned u4[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) u4[p] = pack_bf16((a[8 * s + 2 * p] - mean) * rstd, (a[8 * s + 2 * p + 1] - mean) * rstd);
+                act[s] = __builtin_bit_cast(f32x4, uint4{u4[0], u4[1], u4[2], u4[3]});
+            }
+        }
+        // the residual rows: in flight while the chunks run
+        float4 xr[C / 8];
+        {
+            const float* xp = x + mrow * C + 4 * hh;
+#pragma unroll
+            for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xr[4 * t + q] = *reinterpret_cast<const float4*>(xp + 32 * t + 8 * q);
+        }
+        if (tile + tstride < ntiles) ACX_LOAD_Y(tile + tstride)
+        f32x16 acc[Cfg::kTiles];
+#pragma unroll
+        for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+#pragma nounroll
+        for (int k = 0; k < n; ++k) {
+            const char* base1 = smem + (k == 0 ? 0 : 2 * k - 1) * Cfg::kSegBytes;
+            const char* base2 = smem + (k == n - 1 ? 2 * n - 1 : 2 * k + 2) * Cfg::kSegBytes;
+            f32x16 X[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 64 * k + 32 * j + 8 * q + 4 * hh);
+                    X[j][4 * q + 0] = bq[0]; X[j][4 * q + 1] = bq[1]; X[j][4 * q + 2] = bq[2]; X[j][4 * q + 3] = bq[3];
+                }
+#pragma unroll
+            for (int u = 0; u < Cfg::kUnits; ++u) {
+                const f32x4 f = ACX_W1_RD(base1, u);
+                X[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ACX_B8(f), ACX_B8(act[u >> 1]), X[u & 1], 0, 0, 0);
+            }
+            // GELU + bf16 pack: k-step s' = 2 j + (pair >> 2) of phase 2 takes pairs 4 (s' & 1) .. + 3 of X tile j
+            f32x4 g[4];
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+                unsigned un[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    GeluState gs;
+                    unsigned dummy;
+                    gs.ax = X[sp >> 1][2 * (4 * (sp & 1) + p)]; gs.ay = X[sp >> 1][2 * (4 * (sp & 1) + p) + 1];
+                    gelu_micro<0, true>(gs, gk, dummy, dummy); gelu_micro<1, true>(gs, gk, dummy, dummy); gelu_micro<2, true>(gs, gk, dummy, dummy);
+                    gelu_micro<3, true>(gs, gk, dummy, dummy); gelu_micro<4, true>(gs, gk, dummy, dummy); gelu_micro<5, true>(gs, gk, dummy, dummy);
+                    gelu_micro<6, true>(gs, gk, dummy, dummy);
+                    un[p] = pack_bf16(gs.gx, gs.gy);
+                }
+                g[sp] = __builtin_bit_cast(f32x4, uint4{un[0], un[1], un[2], un[3]});
+            }
+#pragma unroll
+            for (int u = 0; u < Cfg::kUnits; ++u) {
+                const f32x4 f = ACX_W2_RD(base2, u);
+                acc[u >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ACX_B8(f), ACX_B8(g[u & 3]), acc[u >> 2], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue: lane (px, hh), tile t, q: channels 32 t + 8 q + 4 hh .. + 3  ->  x = x + out + b2 ----
+        if constexpr (LNOUT) {
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b2s + 32 * t + 8 * q + 4 * hh);
+                    const float4 v = xr[4 * t + q];
+                    acc[t][4 * q + 0] += v.x + bb.x; acc[t][4 * q + 1] += v.y + bb.y;
+                    acc[t][4 * q + 2] += v.z + bb.z; acc[t][4 * q + 3] += v.w + bb.w;
+                    sum += (acc[t][4 * q + 0] + acc[t][4 * q + 1]) + (acc[t][4 * q + 2] + acc[t][4 * q + 3]);
+                }
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / C);
+            float d = 0.f;
+#pragma unroll
+            for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float u = acc[t][r] - mean; d = fmaf(u, u, d); }
+            d += __shfl_xor(d, 32);
+            const float rstd = 1.0f / sqrtf(d * (1.0f / C) + 1e-6f);
+            if (valid) {
+                __bf16* op = ln_out + mrow * (long long)ld_out + 4 * hh;
+#pragma unroll
+                for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint2 o;
+                        o.x = pack_bf16((acc[t][4 * q + 0] - mean) * rstd, (acc[t][4 * q + 1] - mean) * rstd);
+                        o.y = pack_bf16((acc[t][4 * q + 2] - mean) * rstd, (acc[t][4 * q + 3] - mean) * rstd);
+                        *reinterpret_cast<uint2*>(op + 32 * t + 8 * q) = o;
+                    }
+                for (int c = C + 4 * hh; c < ld_out; c += 8)      // zero the K padding of the downsample GEMM's operand rows
+                    *reinterpret_cast<uint2*>(ln_out + mrow * (long long)ld_out + c) = uint2{0u, 0u};
+            }
+        } else if (valid) {
+            float* xp = x + mrow * C + 4 * hh;
+#pragma unroll
+            for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 32 * t + 8 * q;
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b2s + c + 4 * hh);
+                    float4 v = xr[4 * t + q];
+                    v.x += acc[t][4 * q + 0] + bb.x;
+                    v.y += acc[t][4 * q + 1] + bb.y;
+                    v.z += acc[t][4 * q + 2] + bb.z;
+                    v.w += acc[t][4 * q + 3] + bb.w;
+                    *reinterpret_cast<float4*>(xp + c) = v;
+                }
+        }
+    }
+#undef ACX_B8
+#undef ACX_W1_RD
+#undef ACX_W2_RD
+#undef ACX_LOAD_Y
+}
+
+// number of CUs of the current device (persistent launches), cached per device
+static int cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int v = cached[dev & 63].load(std::memory_order_acquire);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev & 63].store(v, std::memory_order_release);
+    }
+    return v;
+}
+
+template <bool LNOUT>
+static int launch_stat_bf16(const BlockW& w, const float* y, float* x, long long M, void* ln_out, int ld_out, hipStream_t s) {
+    static_assert(WideBfCfg<96, 1>::kSegs * WideBfCfg<96, 1>::kSegBytes + 5 * 96 * 4 <= kCuLdsBytes, "stream does not fit the LDS");
+    static DeviceOnce once;
+    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_stat_bf16_kernel<LNOUT>, kCuLdsBytes));
+    const long long wgs_needed = ((M + 31) / 32 + 7) / 8;
+    const long long blocks = wgs_needed < cu_count() ? wgs_needed : cu_count();
+    mlp_fused_stat_bf16_kernel<LNOUT><<<dim3((unsigned)blocks), dim3(512), kCuLdsBytes /* CU-exclusive */, s>>>(
+        y, x, reinterpret_cast<const char*>(w.wstream_b), w.b1, w.b2, M, ld_out, reinterpret_cast<__bf16*>(ln_out));
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
 bool mlp_fused_wide_bf16_supported(int C) { return C == 384 || C == 192 || C == 96; }
 
 // LDS position of 16-byte chunk p of row `row` of a W1 image (acx_finalize packs the stream with it)
@@ -379,7 +614,7 @@ int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const float* 
     ProfScope ps(c, ACX_K_MLP_WIDE, s);
     if (C == 384) return ln_out ? launch_wide_bf16_cfg<384, 1, true>(w, y, x, M, ln_out, ld_out, s) : launch_wide_bf16_cfg<384, 1, false>(w, y, x, M, nullptr, 0, s);
     if (C == 192) return ln_out ? launch_wide_bf16_cfg<192, 1, true>(w, y, x, M, ln_out, ld_out, s) : launch_wide_bf16_cfg<192, 1, false>(w, y, x, M, nullptr, 0, s);
-    if (C == 96) return ln_out ? launch_wide_bf16_cfg<96, 2, true>(w, y, x, M, ln_out, ld_out, s) : launch_wide_bf16_cfg<96, 2, false>(w, y, x, M, nullptr, 0, s);
+    if (C == 96) return ln_out ? launch_stat_bf16<true>(w, y, x, M, ln_out, ld_out, s) : launch_stat_bf16<false>(w, y, x, M, nullptr, 0, s);
     ACX_FAIL(ACX_ERR_SHAPE, "fused bf16 MLP: unsupported channel count %d", C);
 }
 

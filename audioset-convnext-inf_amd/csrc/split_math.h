@@ -52,7 +52,10 @@ __device__ __forceinline__ void gelu_piece3(f32x2 g, unsigned& hi, unsigned& lo)
 // constants: "1 v_pk_fma_f32 +22 cycles vs 2 v_fma_f32").  |a| is written as fabs at each use so that it folds into
 // the consuming instruction's source modifier.
 struct GeluState { float ax, ay, tx, ty, ex, ey, px, py, gx, gy; };
-template <int STEP>
+// The polynomial carries the factor -0.5 of  gelu = max(v, 0) - 0.5 |v| q  in its coefficients (exact: a power of two), and
+// |v| kH = |a cb| is taken from the scaled value the positive part needs anyway.  UNIT: cb == 1 (bf16 arithmetic: the
+// accumulator holds v itself), the scaling multiply disappears.
+template <int STEP, bool UNIT = false>
 __device__ __forceinline__ void gelu_micro(GeluState& s, const GeluConsts k, unsigned& hi, unsigned& lo) {
     if constexpr (STEP == 0) {
         s.tx = __builtin_fmaf(__builtin_fabsf(s.ax), k.ps, 1.0f);                 // den
@@ -63,20 +66,25 @@ __device__ __forceinline__ void gelu_micro(GeluState& s, const GeluConsts k, uns
     } else if constexpr (STEP == 2) {
         s.ex = __builtin_amdgcn_exp2f(-(s.ex * s.ex)); s.ey = __builtin_amdgcn_exp2f(-(s.ey * s.ey));
     } else if constexpr (STEP == 3) {
-        s.px = __builtin_fmaf(s.tx, 1.061405429f, -1.453152027f); s.py = __builtin_fmaf(s.ty, 1.061405429f, -1.453152027f);
-        s.px = __builtin_fmaf(s.px, s.tx, 1.421413741f); s.py = __builtin_fmaf(s.py, s.ty, 1.421413741f);
+        s.px = __builtin_fmaf(s.tx, -0.5f * 1.061405429f, -0.5f * -1.453152027f); s.py = __builtin_fmaf(s.ty, -0.5f * 1.061405429f, -0.5f * -1.453152027f);
+        s.px = __builtin_fmaf(s.px, s.tx, -0.5f * 1.421413741f); s.py = __builtin_fmaf(s.py, s.ty, -0.5f * 1.421413741f);
     } else if constexpr (STEP == 4) {
-        s.px = __builtin_fmaf(s.px, s.tx, -0.284496736f); s.py = __builtin_fmaf(s.py, s.ty, -0.284496736f);
-        s.px = __builtin_fmaf(s.px, s.tx, 0.254829592f); s.py = __builtin_fmaf(s.py, s.ty, 0.254829592f);
+        s.px = __builtin_fmaf(s.px, s.tx, -0.5f * -0.284496736f); s.py = __builtin_fmaf(s.py, s.ty, -0.5f * -0.284496736f);
+        s.px = __builtin_fmaf(s.px, s.tx, -0.5f * 0.254829592f); s.py = __builtin_fmaf(s.py, s.ty, -0.5f * 0.254829592f);
         s.px *= s.tx; s.py *= s.ty;
     } else if constexpr (STEP == 5) {
-        s.px *= s.ex; s.py *= s.ey;                                               // q
-        s.gx = __builtin_fmaxf(s.ax * k.cb, 0.f); s.gy = __builtin_fmaxf(s.ay * k.cb, 0.f);      // pos
+        s.px *= s.ex; s.py *= s.ey;                                               // -0.5 q
+        if constexpr (!UNIT) { s.gx = s.ax * k.cb; s.gy = s.ay * k.cb; }          // v kH
     } else if constexpr (STEP == 6) {
         // no clamp to the fp16 range: acx_finalize bounds |h| and picks the hidden scale so that it cannot be exceeded
         // (api.hip, hidden_scale_for); were it ever exceeded the result would be inf / NaN -- loud, not silently saturated
-        s.gx = __builtin_fmaf(__builtin_fabsf(s.ax) * k.ca, s.px, s.gx);
-        s.gy = __builtin_fmaf(__builtin_fabsf(s.ay) * k.ca, s.py, s.gy);
+        if constexpr (UNIT) {
+            s.gx = __builtin_fmaf(__builtin_fabsf(s.ax), s.px, __builtin_fmaxf(s.ax, 0.f));
+            s.gy = __builtin_fmaf(__builtin_fabsf(s.ay), s.py, __builtin_fmaxf(s.ay, 0.f));
+        } else {
+            s.gx = __builtin_fmaf(__builtin_fabsf(s.gx), s.px, __builtin_fmaxf(s.gx, 0.f));
+            s.gy = __builtin_fmaf(__builtin_fabsf(s.gy), s.py, __builtin_fmaxf(s.gy, 0.f));
+        }
     } else if constexpr (STEP == 7) {
         f32x2 g; g.x = s.gx; g.y = s.gy;
         const h2 h = __builtin_convertvector(g, h2);

@@ -59,13 +59,16 @@ FUSED_STAGES = (0, 1) if os.environ.get("ACX_DISABLE_FUSED_MLP", "0") != "1" els
 # fp32_split: stage 0 runs mlp_fused_split_kernel<96> (class mlp_fused), stages 1-2 mlp_fused_wide_kernel (class mlp_wide),
 # stage 3 the LayerNorm pass + two gemm_split_kernel launches per block
 SPLIT_FUSED_STAGES, SPLIT_WIDE_STAGES = ((0,), (1, 2)) if FUSED_STAGES else ((), ())
+# bf16: stages 0-2 run mlp_fused_wide_bf16_kernel (class mlp_wide), stage 3 LN->bf16 rows + two gemm_bf16_kernel launches
+BF16_WIDE_STAGES = (0, 1, 2) if FUSED_STAGES else ()
 
 
 def algorithmic_work(B, L, precision="fp32"):
     """Per kernel class: (total FLOPs, total algorithmic HBM bytes) of ONE forward.
     fp32 / fp32_split: stages 0-1 run the fused MLP kernel (hidden activation stays on chip), stages 2-3 the two
     GEMMs (split: plus the LayerNorm -> S16 pass in front of pwconv1).
-    bf16: every block is LN->bf16 rows (counted under rowstats), pwconv1 (bf16 in, bf16 hidden out), pwconv2."""
+    bf16: stages 0-2 run mlp_fused_wide_bf16_kernel (class mlp_wide; the hidden activation stays on chip), stage 3 is
+    LN->bf16 rows (counted under rowstats), pwconv1 (bf16 in, bf16 hidden out), pwconv2."""
     T = L // 320 + 1
     hs = [(T + 4) // 4 + 1]
     ws = [56]
@@ -91,6 +94,9 @@ def algorithmic_work(B, L, precision="fp32"):
             work["pw1"][1] += n * (pix[s] * C * 4 + pix[s] * 4 * C * 4)
             work["pw2"][0] += n * 2.0 * pix[s] * C * 4 * C
             work["pw2"][1] += n * (pix[s] * 4 * C * 4 + 2.0 * pix[s] * C * 4)
+        elif precision == "bf16" and s in BF16_WIDE_STAGES:
+            work["mlp_wide"][0] += n * 4.0 * pix[s] * C * 4 * C
+            work["mlp_wide"][1] += n * 3.0 * pix[s] * C * 4                    # y in, x in, x out
         elif precision == "bf16":
             Cp = (C + 63) // 64 * 64
             work["rowstats"][1] += n * (pix[s] * C * 4 + pix[s] * Cp * 2)
@@ -111,8 +117,9 @@ def algorithmic_work(B, L, precision="fp32"):
             work["downsample"][0] += 2.0 * pix[s] * 4 * DIMS[s - 1] * C
             esz = 2 if precision == "bf16" else 4
             work["downsample"][1] += pix[s - 1] * DIMS[s - 1] * esz + pix[s] * C * 4
-            if not (precision == "fp32_split" and ((s - 1) in SPLIT_FUSED_STAGES or (s - 1) in SPLIT_WIDE_STAGES)):
-                # (in fp32_split the last fused block of the previous stage writes the normalised rows itself)
+            if not ((precision == "fp32_split" and ((s - 1) in SPLIT_FUSED_STAGES or (s - 1) in SPLIT_WIDE_STAGES))
+                    or (precision == "bf16" and (s - 1) in BF16_WIDE_STAGES)):
+                # (in fp32_split / bf16 the last fused block of the previous stage writes the normalised rows itself)
                 work["rowstats"][1] += pix[s - 1] * DIMS[s - 1] * (4 + (esz if precision != "fp32" else 0))
     work["poolhead"] = [2.0 * B * 768 * 527, pix[3] * 768 * 4]
     return work
@@ -360,7 +367,8 @@ def main():
         fused_name = {"fp32": "mlp_fused_kernel", "bf16": "mlp_fused_bf16_kernel", "fp32_split": "mlp_fused_split_kernel"}[args.precision]
         groups = {gemm_name + " (pwconv1+GELU and pwconv2+residual launches, two-GEMM stages)": ("pw1", "pw2"),
                   fused_name + " (LN+pwconv1+GELU+pwconv2+residual in one launch)": ("mlp_fused",),
-                  "mlp_fused_wide_kernel (LN+pwconv1+GELU+pwconv2+residual in one launch, stages 1-2)": ("mlp_wide",)}
+                  ("mlp_fused_wide_bf16_kernel (LN+pwconv1+GELU+pwconv2+residual in one launch, stages 0-2)" if bf16 else
+                   "mlp_fused_wide_kernel (LN+pwconv1+GELU+pwconv2+residual in one launch, stages 1-2)"): ("mlp_wide",)}
         merged = {}
         for name, ks in groups.items():
             ks = [k for k in ks if k in kernels]
