@@ -141,7 +141,7 @@ struct acx_ctx {
     float* d_head_b = nullptr;    // [527]
 
     int precision = ACX_PREC_F32_SPLIT;   // acx_set_precision (include/acx.h): the default equals the Python host's
-    bool use_fused_mlp = true;    // ACX_DISABLE_FUSED_MLP=1 turns the fused stage-0/1 MLP kernel off
+    bool use_fused_mlp = true;    // ACX_DISABLE_FUSED_MLP=1 (native fp32 arithmetic only) turns the fused stage-0/1 MLP kernel off
     // two-way batch split over two HIP streams (fork/join by events): kernels of the two halves co-run, so
     // an HBM-bound kernel of one half fills the matrix-pipe-bound phases of the other and vice versa
     bool split_streams = true;    // ACX_SPLIT_STREAMS=0 turns it off

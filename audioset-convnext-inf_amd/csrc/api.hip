@@ -188,8 +188,9 @@ static int finalize_impl(acx_ctx* c) {
     ACX_HIP(hipSetDevice(c->device));
     free_device(c);
     {
+        // the two-GEMM form of stages 0-1 exists in the native fp32 arithmetic only (the 16-bit GEMMs have no N = 96 tile)
         const char* e = std::getenv("ACX_DISABLE_FUSED_MLP");
-        c->use_fused_mlp = !(e && e[0] == '1');
+        c->use_fused_mlp = !(e && e[0] == '1' && c->precision == ACX_PREC_F32);
     }
 
     // ---- frontend ---------------------------------------------------------------------------

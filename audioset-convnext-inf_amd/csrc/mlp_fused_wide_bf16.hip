@@ -206,21 +206,19 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
         const bool dma = seg_ + 2 < Cfg::kSegs;
         const int g2 = (grp_ + 2) % 3;
         ACX_BIAS_INIT(k_)
-        f32x4 f0 = ACX_W1_RD(base, 0), f1;
+        // fragment reads run TWO units ahead of their MFMA (three rotating buffers): at one MFMA per fragment the ~100
+        // cycles of a ds_read_b128 do not fit behind a single 32-cycle MFMA and its share of the GELU
+        f32x4 f[3];
+        f[0] = ACX_W1_RD(base, 0);
+        f[1] = ACX_W1_RD(base, 1);
 #pragma unroll
-        for (int u = 0; u < Cfg::kUnits; u += 2) {
-            f1 = ACX_W1_RD(base, u + 1);
+        for (int u = 0; u < Cfg::kUnits; ++u) {
+            if (u + 2 < Cfg::kUnits) f[(u + 2) % 3] = ACX_W1_RD(base, u + 2);
             ACX_FENCE
-            ACX_P1_MFMA(u, f0)
+            ACX_P1_MFMA(u, f[u % 3])
             if (u % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, u / kDmaStride, g2) }
             ACX_FENCE
-            ACX_TOUCH1(f1)
-            if (u + 2 < Cfg::kUnits) f0 = ACX_W1_RD(base, u + 2);
-            ACX_FENCE
-            ACX_P1_MFMA(u + 1, f1)
-            if ((u + 1) % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (u + 1) / kDmaStride, g2) }
-            ACX_FENCE
-            if (u + 2 < Cfg::kUnits) ACX_TOUCH1(f0)
+            if (u + 1 < Cfg::kUnits) ACX_TOUCH1(f[(u + 1) % 3])
         }
         if constexpr (HV) { ACX_PACK_G() }
 #pragma unroll
@@ -232,21 +230,17 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
         const char* base = smem + grp_ * Cfg::kSegBytes;
         const bool dma = seg_ + 2 < Cfg::kSegs;
         const int g2 = (grp_ + 2) % 3;
-        f32x4 f0 = ACX_W2_RD(base, 0), f1;
+        f32x4 f[3];
+        f[0] = ACX_W2_RD(base, 0);
+        f[1] = ACX_W2_RD(base, 1);
 #pragma unroll
-        for (int u = 0; u < Cfg::kUnits; u += 2) {
-            f1 = ACX_W2_RD(base, u + 1);
+        for (int u = 0; u < Cfg::kUnits; ++u) {
+            if (u + 2 < Cfg::kUnits) f[(u + 2) % 3] = ACX_W2_RD(base, u + 2);
             ACX_FENCE
-            ACX_P2_MFMA(u, f0)
+            ACX_P2_MFMA(u, f[u % 3])
             if (u % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, u / kDmaStride, g2) }
             ACX_FENCE
-            ACX_TOUCH1(f1)
-            if (u + 2 < Cfg::kUnits) f0 = ACX_W2_RD(base, u + 2);
-            ACX_FENCE
-            ACX_P2_MFMA(u + 1, f1)
-            if ((u + 1) % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (u + 1) / kDmaStride, g2) }
-            ACX_FENCE
-            if (u + 2 < Cfg::kUnits) ACX_TOUCH1(f0)
+            if (u + 1 < Cfg::kUnits) ACX_TOUCH1(f[(u + 1) % 3])
         }
         ACX_SEG_END(dma)
     };

@@ -58,9 +58,9 @@ DIMS, DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
 FUSED_STAGES = (0, 1) if os.environ.get("ACX_DISABLE_FUSED_MLP", "0") != "1" else ()
 # fp32_split: stage 0 runs mlp_fused_split_kernel<96> (class mlp_fused), stages 1-2 mlp_fused_wide_kernel (class mlp_wide),
 # stage 3 the LayerNorm pass + two gemm_split_kernel launches per block
-SPLIT_FUSED_STAGES, SPLIT_WIDE_STAGES = ((0,), (1, 2)) if FUSED_STAGES else ((), ())
+SPLIT_FUSED_STAGES, SPLIT_WIDE_STAGES = (0,), (1, 2)       # (the switch above acts on the native fp32 arithmetic only)
 # bf16: stages 0-2 run mlp_fused_wide_bf16_kernel (class mlp_wide), stage 3 LN->bf16 rows + two gemm_bf16_kernel launches
-BF16_WIDE_STAGES = (0, 1, 2) if FUSED_STAGES else ()
+BF16_WIDE_STAGES = (0, 1, 2)
 
 
 def algorithmic_work(B, L, precision="fp32"):
@@ -388,6 +388,8 @@ def main():
         avg_launch_s = g["ms"] * 1e-3 / g["launches"]
         ach = per_launch_flops / avg_launch_s / 1e12
         traffic, traffic_src = measured_traffic()
+        if bf16:            # the committed PMC summary the bench reads is the default precision's
+            traffic, traffic_src = {}, None
         tr = lambda k: (traffic.get(k, {}).get("hbm_traffic_bytes_per_launch") if B == 64 else None)
         dom_classes = [k for k in groups[dom] if k in kernels]
         tr_dom = [tr(k) for k in dom_classes]

@@ -66,14 +66,18 @@ def ln_plain(x, C):
     return F.layer_norm(x, (C,), None, None, 1e-6)
 
 
+@pytest.mark.parametrize("rows", [None, 3])
 @pytest.mark.parametrize("s", [0, 1, 2, 3])
-def test_block_bf16(ctx16, taps, synth_sd, s):
+def test_block_bf16(ctx16, taps, synth_sd, s, rows):
     from oracle import ref_cpu
     C = DIMS[s]
     p = "stages.%d.0." % s
     x0 = taps["ds%d" % s]                                  # NCHW fp32
+    if rows is not None:                                   # 3 x W pixels of one clip: not a multiple of any kernel's row tile
+        x0 = x0[:1, :, :rows, :].contiguous()
     y = ref_cpu.block_dwconv(synth_sd, s, 0, x0).permute(0, 2, 3, 1)
-    # the arithmetic of run_mlp_bf16 (api.hip): folds in fp32/fp64, operands rounded to bf16, wide accumulation
+    # the arithmetic of the bf16 block kernels (mlp_fused_wide_bf16.hip; stage 3: run_mlp_bf16 in api.hip): folds in
+    # fp32/fp64, operands rounded to bf16, wide accumulation
     yn = bf(ln_plain(y, C))
     w1 = bf((synth_sd[p + "pwconv1.weight"].double() * synth_sd[p + "norm.weight"].double()[None, :]).float())
     b1 = synth_sd[p + "pwconv1.bias"].double() + synth_sd[p + "pwconv1.weight"].double() @ synth_sd[p + "norm.bias"].double()
@@ -90,10 +94,11 @@ def test_block_bf16(ctx16, taps, synth_sd, s):
     _ffi.check(_ffi.lib().acx_block(ctx16.handle, s, 0, _ffi.ptr(x), B, H, W, _ffi.ptr(scratch), need.value, sp()))
     torch.cuda.synchronize()
     d_emu = maxdiff(x, ref)
-    d_f32 = maxdiff(x.permute(0, 3, 1, 2), taps["s%d.b0.out" % s])
-    print("stage %d: vs bf16 emulation %.3g, vs fp32 tap %.3g" % (s, d_emu, d_f32))
     assert d_emu < EMU_TOL
-    assert d_f32 < DRIFT_LAYER_TOL
+    if rows is None:
+        d_f32 = maxdiff(x.permute(0, 3, 1, 2), taps["s%d.b0.out" % s])
+        print("stage %d: vs bf16 emulation %.3g, vs fp32 tap %.3g" % (s, d_emu, d_f32))
+        assert d_f32 < DRIFT_LAYER_TOL
 
 
 @pytest.mark.parametrize("i", [1, 2, 3])
@@ -145,6 +150,31 @@ def test_bf16_batch_rows_independent(model16):
     assert bool(torch.isfinite(out).all())
     solo = model16(wav[11:12])["clipwise_logits"]
     assert torch.equal(solo[0], out[11])
+
+
+def test_bf16_ragged_clip_lengths(synth_sd):
+    """Clip lengths whose pixel counts are not multiples of the kernels' row tiles (32 / 128 / 256 rows), through the whole
+    forward (fused block kernels incl. the last block of a stage writing the downsample conv's operand rows): finite,
+    batch == solo bit for bit, and within the bf16 drift of the fp32-grade result."""
+    from audioset_convnext_inf_amd import synth
+    m = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
+                      use_speed_perturb=False)
+    m.load_state_dict(synth_sd)
+    m = m.to("cuda").eval()
+    for B, L in ((3, 43840), (1, 30000), (5, 52000)):
+        wav = synth.synth_waveforms(B, L, seed=B).cuda()
+        m.set_precision("fp32_split")
+        ref = m(wav)["clipwise_logits"].clone()
+        ref_fr = m.forward_frame_embeddings(wav).clone()
+        m.set_precision("bf16")
+        a = m(wav)["clipwise_logits"].clone()
+        fr = m.forward_frame_embeddings(wav).clone()
+        assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(fr).all())
+        solo = m(wav[B - 1:B])["clipwise_logits"]
+        assert torch.equal(solo[0], a[B - 1])
+        d, dfr = maxdiff(a, ref), maxdiff(fr, ref_fr)
+        print("B=%d L=%d: bf16 vs fp32_split: logits %.3g frame %.3g" % (B, L, d, dfr))
+        assert d < DRIFT_E2E_TOL and dfr < 2 * DRIFT_E2E_TOL
 
 
 def test_precision_switch_rebuilds_context(synth_sd):

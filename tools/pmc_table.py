@@ -6,7 +6,8 @@ usage: pmc_table.py <dir_sq> <dir_fetch> <dir_write> <out_csv> <out_json>"""
 import collections, csv, glob, json, sys
 
 def load(d):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    import os
+    f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)     # gpurun merges into a directory that may hold older runs
     out = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         e = out.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "grid": r["Grid_Size"],
@@ -17,7 +18,7 @@ def load(d):
     return rows[idx[-1]:]           # the last forward only
 
 def cls(name):
-    for key, c in (("logmel", "frontend"), ("stem_kernel", "stem"), ("dwconv7", "dwconv"), ("mlp_fused_wide", "mlp_wide"), ("mlp_fused", "mlp_fused"),
+    for key, c in (("logmel", "frontend"), ("stem_kernel", "stem"), ("dwconv7", "dwconv"), ("mlp_fused_wide", "mlp_wide"), ("mlp_fused_stat", "mlp_wide"), ("mlp_fused", "mlp_fused"),
                    ("rowstats", "rowstats"), ("pool_head", "poolhead"), ("nhwc_to_nchw", "transpose")):
         if key in name:
             return c
