@@ -21,7 +21,7 @@
 // The workgroup is CU-EXCLUSIVE (acx_internal.h, kCuLdsBytes): it claims all 160 KB of LDS and 512 x 256 registers, so no
 // foreign wave can be co-resident with its MFMA loop (packed-FP32 VALU work of a co-resident wave goes wrong next to
 // it on this platform -- tools/race2/).  A k-tile is only 2 x TM*TN*3 MFMAs of 32 cycles, so
-// the pipeline is one k-tile deeper than the fp32 kernel's: tile t+2 is in flight while tile t is multiplied.
+// the pipeline is deeper than the fp32 kernel's: B tile t+2 and A tiles t+2, t+3 are in flight while tile t is multiplied.
 #include "acx_internal.h"
 #include "split_math.h"
 
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
     constexpr bool SWAP = true;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
-    char* Bs = smem + 2 * A_TILE;
+    char* Bs = smem + 3 * A_TILE;        // A: ring of three k-tiles, B: two (see the k loop)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -165,41 +165,44 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         _Pragma("unroll") for (int j = 0; j < TN; ++j) { ACX_MFMA1(term, i, j, F) }                    \
         ACX_PRIO_LO                                                                                    \
     }
-    // the same with the LDS-DMA pieces of a later tile threaded in, one piece in front of each MFMA
-#define ACX_MFMA_STEP_DMA(F, koffA, k0B, buf)                                                          \
+    // the same with LDS-DMA pieces threaded in, one piece per MFMA in program order (hipcc may move a piece by an MFMA or
+    // two; scheduling fences around every pair cost 5 %): first the B pieces of tile t+2, then -- behind one fence -- the A
+    // pieces of tile t+3 (the counted wait at the next barrier relies on this order, see the k loop)
+#define ACX_MFMA_STEP_DMA(F, koffA, aslot, k0B, bslot)                                                 \
     {                                                                                                  \
         static_assert(A_DMA + B_DMA <= 3 * TM * TN, "one DMA piece per MFMA");                         \
         _Pragma("unroll") for (int term = 0; term < 3; ++term)                                         \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                               \
             const int pc = (term * TM + i) * TN + j;                                                   \
-            if (pc < A_DMA) lds_dma16_s(a_src[pc] + (koffA), a_dst + (buf) * A_TILE + pc * 8 * kSRowBytes); \
+            if (pc == B_DMA) __builtin_amdgcn_sched_barrier(0);      /* every B piece is issued before the first A piece */ \
+            if (pc < B_DMA) lds_dma16_s(b_src[pc] + (k0B), b_dst + (bslot) * B_TILE + pc * 8 * kSRowBytes); \
             else if (pc < A_DMA + B_DMA)                                                               \
-                lds_dma16_s(b_src[pc - A_DMA] + (k0B), b_dst + (buf) * B_TILE + (pc - A_DMA) * 8 * kSRowBytes); \
-            __builtin_amdgcn_sched_barrier(0);                                                         \
+                lds_dma16_s(a_src[pc - B_DMA] + (koffA), a_dst + (aslot) * A_TILE + (pc - B_DMA) * 8 * kSRowBytes); \
             ACX_MFMA1(term, i, j, F)                                                                   \
-            __builtin_amdgcn_sched_barrier(0);                                                         \
         }                                                                                              \
     }
-#define ACX_DMA_TILE(koffA, k0B, buf)                                                                  \
-    {                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < A_DMA; ++i)                                              \
-            lds_dma16_s(a_src[i] + (koffA), a_dst + (buf) * A_TILE + i * 8 * kSRowBytes);              \
-        _Pragma("unroll") for (int i = 0; i < B_DMA; ++i)                                              \
-            lds_dma16_s(b_src[i] + (k0B), b_dst + (buf) * B_TILE + i * 8 * kSRowBytes);                \
-    }
+#define ACX_DMA_A(koffA, aslot)                                                                        \
+    {   _Pragma("unroll") for (int i = 0; i < A_DMA; ++i)                                              \
+            lds_dma16_s(a_src[i] + (koffA), a_dst + (aslot) * A_TILE + i * 8 * kSRowBytes); }
+#define ACX_DMA_B(k0B, bslot)                                                                          \
+    {   _Pragma("unroll") for (int i = 0; i < B_DMA; ++i)                                              \
+            lds_dma16_s(b_src[i] + (k0B), b_dst + (bslot) * B_TILE + i * 8 * kSRowBytes); }
 #define ACX_TOUCH(F)      /* see gemm.hip: keeps hipcc's lgkmcnt(0) off freshly issued reads */        \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) { asm volatile("" :: "v"(F##ah[i])); asm volatile("" :: "v"(F##al[i])); } \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) { asm volatile("" :: "v"(F##bh[j])); asm volatile("" :: "v"(F##bl[j])); } \
     }
 
-#define ACX_LOOP_BARRIER __syncthreads();
     const int nk = p.K / kSBK;
-    // prologue: tiles 0 and 1 in flight, fragments of tile 0 in registers
-    ACX_DMA_TILE(a_koff(0), 0LL, 0)
+    auto ktile = [&](int t) { return (t < nk ? t : nk - 1) * kSBK; };      // past the end: re-request the last tile (harmless, keeps the loop uniform)
+    // prologue: tile 0 landed; then B(1), A(1), A(2) in flight -- in THIS order -- and the fragments of tile 0 in registers
+    ACX_DMA_A(a_koff(0), 0)
+    ACX_DMA_B(0LL, 0)
     __syncthreads();
-    ACX_DMA_TILE(a_koff(kSBK), (long long)kSBK * 4, 1)         // nk >= 2 (checked by the launcher)
+    ACX_DMA_B((long long)ktile(1) * 4, 1)                      // nk >= 2 (checked by the launcher)
+    ACX_DMA_A(a_koff(ktile(1)), 1)
+    ACX_DMA_A(a_koff(ktile(2)), 2)
     f32x4 F0ah[TM], F0al[TM], F0bh[TN], F0bl[TN], F1ah[TM], F1al[TM], F1bh[TN], F1bl[TN];
     {
         const char* ab = As + a_frag_off;
@@ -207,50 +210,46 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
         ACX_READ_FRAGS(F0, ab, bb, 0)
         ACX_READ_FRAGS(F1, ab, bb, 1)
     }
-    // steady state, tile t:  MFMA s0 | barrier (tile t+1 landed, tile t fully read) | rd s0(t+1) |
-    //                        MFMA s1 threaded with DMA(t+2 -> buffer of t) | rd s1(t+1)
-    // (no conditional inside the loop: a branch around the DMA variant makes hipcc copy all accumulators twice
-    //  per iteration)
-    int kt = 0;
-    for (; kt + 2 < nk; ++kt) {
-        const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
+    // steady state, tile t (A slot t % 3, B slot t & 1):
+    //   MFMA s0 | counted wait + barrier (tile t+1 landed, tile t fully read by every wave) | rd s0(t+1) |
+    //   MFMA s1 threaded with DMA B(t+2) -> B slot of t, then DMA A(t+3) -> A slot of t | rd s1(t+1)
+    // The activations (A) come from HBM / the Infinity Cache: with a 2-slot ring a request had ONE k-tile (~1 us) to land
+    // and the loop spent half its time in the barrier's wait; the third A slot gives it two.  One wave's vector-memory
+    // counter retires in issue order, so "tile t+1 landed" = everything but the newest A_DMA pieces (those of A(t+2),
+    // issued last in the previous iteration) has returned: s_waitcnt vmcnt(A_DMA).
+    // (no conditional inside the loop: a branch around the DMA variant makes hipcc copy all accumulators twice per
+    //  iteration; past the last tile the requests repeat tile nk-1 into slots nobody reads again)
+    int a_cur = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int a_nxt = a_cur == 2 ? 0 : a_cur + 1;
+        const char* abn = As + a_nxt * A_TILE + a_frag_off;
         const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
-        const int k2 = (kt + 2) * kSBK;
-        const long long ka = a_koff(k2);
+        const long long kb = (long long)ktile(kt + 2) * 4;
+        const long long ka = a_koff(ktile(kt + 3));
         __builtin_amdgcn_sched_barrier(0);
         ACX_MFMA_STEP(F0)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(F1)
-        ACX_LOOP_BARRIER
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_DMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         ACX_READ_FRAGS(F0, abn, bbn, 0)
         __builtin_amdgcn_sched_barrier(0);
-        ACX_MFMA_STEP_DMA(F1, ka, (long long)k2 * 4, kt & 1)
+        ACX_MFMA_STEP_DMA(F1, ka, a_cur, kb, kt & 1)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(F0)
         ACX_READ_FRAGS(F1, abn, bbn, 1)
-    }
-    {   // tile nk-2: nothing left to fetch
-        const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
-        const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
-        __builtin_amdgcn_sched_barrier(0);
-        ACX_MFMA_STEP(F0)
-        __builtin_amdgcn_sched_barrier(0);
-        ACX_TOUCH(F1)
-        ACX_LOOP_BARRIER
-        ACX_READ_FRAGS(F0, abn, bbn, 0)
-        __builtin_amdgcn_sched_barrier(0);
-        ACX_MFMA_STEP(F1)
-        __builtin_amdgcn_sched_barrier(0);
-        ACX_TOUCH(F0)
-        ACX_READ_FRAGS(F1, abn, bbn, 1)
+        a_cur = a_nxt;
     }
     ACX_MFMA_STEP(F0)
     ACX_MFMA_STEP(F1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the repeated requests of the last iterations: nothing may still be writing the LDS when the workgroup ends
 #undef ACX_READ_FRAGS
 #undef ACX_MFMA1
 #undef ACX_MFMA_STEP
 #undef ACX_MFMA_STEP_DMA
-#undef ACX_DMA_TILE
+#undef ACX_DMA_A
+#undef ACX_DMA_B
 #undef ACX_TOUCH
 #undef ACX_H8
 
@@ -338,7 +337,7 @@ static int launch_s_cfg(const GemmSParams& p0, hipStream_t s) {
     const long long tiles_m = (p.M + kBM - 1) / kBM;
     const long long blocks = tiles_m * p.tiles_n;
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: grid too large");
-    static_assert((size_t)2 * (kBM + BN) * kSRowBytes <= kCuLdsBytes, "tile does not fit the LDS");
+    static_assert((size_t)(3 * kBM + 2 * BN) * kSRowBytes <= kCuLdsBytes, "tile does not fit the LDS");
     constexpr size_t lds = kCuLdsBytes;          // all of it: CU-exclusive (see the header comment)
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER>, lds));
