@@ -214,6 +214,7 @@ bool mlp_fused_supported(int C);
 // x += MLP(LN(y)) for one block, hidden activation kept in registers (mlp_fused.hip)
 int launch_mlp_fused(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s);
 // ln_out != nullptr: do not write x; write LayerNorm(x_new) as S16 rows (the downsample GEMM's operand) there instead
+bool mlp_fused_split_supported(int C);
 int launch_mlp_fused_split(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
                            void* ln_out = nullptr);
 // the same for wide stages (C = 384, mlp_fused_wide.hip): one wave per SIMD, weights as one stream of segments

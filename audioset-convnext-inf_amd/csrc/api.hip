@@ -350,7 +350,7 @@ static int finalize_impl(acx_ctx* c) {
                 const std::vector<uint16_t> h1 = s16_rows(f1, 4 * C, C, bw.w1s_scale);
                 ACX_TRY(upload(c, h1, &bw.w1s));
                 ACX_TRY(upload(c, s16_rows(f2, C, 4 * C, bw.w2s_scale), &bw.w2s));
-                if (mlp_fused_supported(C)) {
+                if (mlp_fused_split_supported(C)) {
                     // chunk-major image for mlp_fused_split.hip: per chunk j [W1c = rows 32j..32j+31 of w1s]
                     // [W2c: C rows x 4 blocks; block b = 2s'+h holds hidden units 32j + 16s' + 4h + 8(jj>>2) + (jj&3)]
                     const int nch = 4 * C / 32;
@@ -505,7 +505,7 @@ static int run_mlp_split(acx_ctx* c, const BlockW& bw, int C, float* y, float* x
 static bool block_can_emit_ln(const acx_ctx* c, int s) {
     if (s < 3 && c->precision == ACX_PREC_BF16 && c->use_fused_mlp && mlp_fused_wide_bf16_supported(kDims[s])) return true;
     return s < 3 && c->precision == ACX_PREC_F32_SPLIT && c->use_fused_mlp &&
-           (mlp_fused_supported(kDims[s]) || mlp_fused_wide_supported(kDims[s]));
+           (mlp_fused_split_supported(kDims[s]) || mlp_fused_wide_supported(kDims[s]));
 }
 
 static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden, float* stats, int B, int H, int Wd,
@@ -516,7 +516,7 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     if (c->precision == ACX_PREC_F32_SPLIT) {
         ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
         if (c->use_fused_mlp && mlp_fused_wide_supported(C) && bw.wstream_s) return launch_mlp_fused_wide(c, bw, C, y, x, M, st, ln_out);
-        if (c->use_fused_mlp && mlp_fused_supported(C)) return launch_mlp_fused_split(c, bw, C, y, x, M, st, ln_out);
+        if (c->use_fused_mlp && mlp_fused_split_supported(C)) return launch_mlp_fused_split(c, bw, C, y, x, M, st, ln_out);
         if (ln_out) ACX_FAIL(ACX_ERR_STATE, "run_block: LayerNorm output requested from a two-GEMM stage");
         return run_mlp_split(c, bw, C, y, x, hidden, M, st);
     }

@@ -434,12 +434,13 @@ static int launch_fused_s_cfg(const BlockW& w, const float* y, float* x, long lo
     return ACX_OK;
 }
 
+bool mlp_fused_split_supported(int C) { return C == 96; }     // (C = 192, 384: mlp_fused_wide.hip)
+
 int launch_mlp_fused_split(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
                            void* ln_out) {
     if (!w.wpack_s) ACX_FAIL(ACX_ERR_STATE, "fused split MLP: chunk-major S16 weights were not packed for C=%d", C);
     ProfScope ps(c, ACX_K_MLP_FUSED, s);
     if (C == 96) return ln_out ? launch_fused_s_cfg<96, true>(w, y, x, M, ln_out, s) : launch_fused_s_cfg<96, false>(w, y, x, M, nullptr, s);
-    if (C == 192) return ln_out ? launch_fused_s_cfg<192, true>(w, y, x, M, ln_out, s) : launch_fused_s_cfg<192, false>(w, y, x, M, nullptr, s);
     ACX_FAIL(ACX_ERR_SHAPE, "fused split MLP: unsupported channel count %d", C);
 }
 

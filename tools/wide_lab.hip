@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
         hipMemcpy(w, hw.data(), wbytes, hipMemcpyHostToDevice);
     }
     acx::BlockW bw;
-    bw.wstream_s = reinterpret_cast<uint16_t*>(w); bw.b1 = b1; bw.b2 = b2; bw.w1s_scale = 1.f; bw.w2s_scale = 1.f; bw.hid_scale = 16.f;
+    bw.wstream_s = reinterpret_cast<uint16_t*>(w); bw.wpack_s = reinterpret_cast<uint16_t*>(w); /* (mlp_fused_split.hip reads wpack_s) */ bw.b1 = b1; bw.b2 = b2; bw.w1s_scale = 1.f; bw.w2s_scale = 1.f; bw.hid_scale = 16.f;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 5; ++i) if (acx::WIDE_FN(nullptr, bw, C, y, x, M, 0) != 0) return 1;
     hipDeviceSynchronize();
