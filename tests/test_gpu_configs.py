@@ -183,6 +183,39 @@ def test_concurrent_forwards_on_two_streams(synth_sd):
         assert torch.equal(o1, r1) and torch.equal(o2, r2)
 
 
+@pytest.mark.parametrize("precision", ["fp32_split", "bf16"])
+def test_forward_beside_foreign_work_on_another_stream(synth_sd, precision):
+    """The round-1 defect: while a dense 16-bit-MFMA kernel ran, FFT-type kernels of OTHER streams (rocFFT included)
+    returned wrong results.  Every such kernel now launches CU-exclusive workgroups; here a forward of
+    the 16-bit arithmetics runs beside torch work on a side stream -- elementwise, softmax (LDS reductions) and rocFFT --
+    and both sides must reproduce their serial results bit for bit."""
+    m = make_model(synth_sd, precision)
+    wav = synth.synth_waveforms(32, 160000, seed=77).cuda()
+    ref_out = m(wav)["clipwise_logits"].clone()
+    v = torch.randn(4096, 4096, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+
+    def victims():
+        a = torch.sin(v) * 2 + 1
+        b = torch.softmax(v, dim=1)
+        c = torch.fft.rfft(v[:2048, :1024], dim=1).abs()
+        return a, b, c
+
+    ref_v = victims()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    wrong_v, wrong_f = 0, 0
+    for _ in range(10):
+        torch.cuda.synchronize()
+        out = m(wav)["clipwise_logits"]           # ~5 ms of kernels queued on the current stream
+        with torch.cuda.stream(side):
+            got = victims()
+        torch.cuda.synchronize()
+        wrong_v += sum(int(not torch.equal(g, r)) for g, r in zip(got, ref_v))
+        wrong_f += int(not torch.equal(out, ref_out))
+    assert wrong_v == 0, "foreign kernels disturbed in %d of 30 results" % wrong_v
+    assert wrong_f == 0, "forward disturbed in %d of 10 runs" % wrong_f
+
+
 def test_logmel_kernel_clamp_cases(model, synth_sd):
     """Kernel level (acx_logmel_bn0): digital silence sits exactly on the -100 dB clamp (10 log10 max(mel, 1e-10),
     convnext.py:190-200) and bn0 maps the clamp value as the reference does; a -80 dBFS tone matches the reference's
