@@ -116,6 +116,28 @@ def test_e2e_stress(model, stress):
     check("frame", model.forward_frame_embeddings(wav), stress["frame32"], stress["frame64"], E2E_TOL)
 
 
+def test_e2e_stress_vs_reference_golden(model, stress, golden_dir):
+    """The same forward against the REFERENCE CLASS's own outputs under these weights (tests/golden/g4_stress.npz,
+    generated by importing the reference in the build container) -- not only against the oracle."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "g4_stress.npz"))
+    wav = torch.from_numpy(g["wav"])
+    assert torch.equal(wav, stress["wav"])
+    wav = wav.cuda()
+    out = model(wav)
+    for name, got, ref64 in (("logits", out["clipwise_logits"], stress["out64"]["clipwise_logits"]),
+                             ("probs", out["clipwise_output"], stress["out64"]["clipwise_output"]),
+                             ("scene", model.forward_scene_embeddings(wav), stress["scene64"]),
+                             ("frame", model.forward_frame_embeddings(wav), stress["frame64"])):
+        ref = torch.from_numpy(g[name])
+        noise = float((ref.double() - ref64).abs().max())            # the reference's own fp32 rounding noise
+        err = float((got.detach().cpu().double() - ref.double()).abs().max())
+        bound = max(E2E_TOL, NOISE_FACTOR * noise)
+        print("%s: |hip - reference| = %.3g, |reference - fp64| = %.3g, bound %.3g" % (name, err, noise, bound))
+        assert err < bound, (name, err, noise)
+
+
 def test_hidden_scale_never_saturates(stress):
     """acx_finalize bounds |pwconv1 output| by Cauchy-Schwarz and scales the fp16 hidden activation accordingly: feed
     the block the worst input the bound allows for (a LayerNorm output aligned with the largest pwconv1 row) and

@@ -67,6 +67,21 @@ def test_oracle_g1_demo(synth_sd, golden_dir):
     np.testing.assert_allclose(ref_cpu.forward_frame_embeddings(synth_sd, wav).numpy(), g["frame"], atol=TOL, rtol=0)
 
 
+def test_oracle_g4_stress(golden_dir):
+    """The oracle against the reference class under the trained-like stress weights (tests/golden/make_stress_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "g4_stress.npz"))
+    m = json.load(open(os.path.join(golden_dir, "MANIFEST_stress.json")))
+    sd = synth.stress_state_dict(0)
+    assert synth.state_dict_digest(sd) == m["weights_sha256"]
+    wav = torch.from_numpy(g["wav"])
+    o = ref_cpu.forward(sd, wav)
+    got = {"logits": o["clipwise_logits"], "probs": o["clipwise_output"],
+           "scene": ref_cpu.forward_scene_embeddings(sd, wav), "frame": ref_cpu.forward_frame_embeddings(sd, wav)}
+    for k, v in got.items():
+        d = float((v.double() - torch.from_numpy(g[k]).double()).abs().max())
+        assert d <= 1e-5 * max(1.0, m["max_abs_reference"][k]), (k, d)
+
+
 def test_shape_contract(golden_dir):
     m = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["shapes"]["g3_lengths"]
     for L in (7360, 96123, 320000, 960000):
