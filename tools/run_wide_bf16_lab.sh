@@ -2,10 +2,11 @@
 # Builds and times ablation variants of mlp_fused_wide_bf16.hip on the GPU box.  Each variant = sed script on the product source.
 # usage: tools/run_wide_bf16_lab.sh [C ...]   (default 96 192 384)
 mkdir -p gpurun_out; O=gpurun_out/wide_bf16_lab.txt; : > $O
-SRC=audioset-convnext-inf_amd/csrc/mlp_fused_wide_bf16.hip
+SRC=${SRC:-audioset-convnext-inf_amd/csrc/mlp_fused_wide_bf16.hip}
 CS=${@:-96 192 384}
 variant() {   # name, sed expression(s)
   local name=$1; shift
+  if [ -n "$ONLY" ] && [[ " $ONLY " != *" $name "* ]]; then return; fi
   cp $SRC /tmp/wide_variant.hip
   for e in "$@"; do sed -i -E "$e" /tmp/wide_variant.hip; done
   cp audioset-convnext-inf_amd/csrc/split_math.h /tmp/split_math_variant.h
@@ -25,6 +26,7 @@ variant gelu_no_trans 's/__builtin_amdgcn_rcpf\(([^)]*)\)/(\1 * 0.5f)/g; s/__bui
 variant no_barrier 's/__builtin_amdgcn_s_barrier\(\);/ /'
 variant one_chunk_pair 's/for \(int k = 1; k < n - 1; \+\+k\) \{/for (int k = 1; k < 2; ++k) {/'
 variant no_ldsread 's/#define ACX_W1_RD\(base_, u_\).*/#define ACX_W1_RD(base_, u_) (act[0][(u_) % 4])/; s/#define ACX_W2_RD\(base_, u_\).*/#define ACX_W2_RD(base_, u_) (act[0][(u_) % 4])/'
+variant ring_hot_rows 's/mrow\[pt\] = \(tile_\) \* Cfg::kPix \+/mrow[pt] = ((tile_) \& 1) * Cfg::kPix +/'
 # the weights-stationary C = 96 kernel
 variant stat_no_gelu 's/gelu_micro<0>\(gs, gk, dummy, dummy\); gelu_micro<1>\(gs, gk, dummy, dummy\); gelu_micro<2>\(gs, gk, dummy, dummy\);/gs.gx = gs.ax; gs.gy = gs.ay;/; s/gelu_micro<[3-6]>\(gs, gk, dummy, dummy\);//g'
 variant stat_one_chunk 's/for \(int k = 0; k < n; \+\+k\) \{/for (int k = 0; k < 1; ++k) {/'
