@@ -217,8 +217,8 @@ def self_launch(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--mode", default="logits", choices=["logits", "scene", "frame"])
     ap.add_argument("--precision", default=os.environ.get("ACX_PRECISION", "fp32_split"), choices=["fp32_split", "fp32", "bf16"],
