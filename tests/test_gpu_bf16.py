@@ -177,6 +177,27 @@ def test_bf16_ragged_clip_lengths(synth_sd):
         assert d < DRIFT_E2E_TOL and dfr < 2 * DRIFT_E2E_TOL
 
 
+def test_bf16_forward_is_graph_capturable(model16):
+    """The bf16 launch path (persistent stage-0 kernel included) neither allocates nor synchronises: capture into a
+    hipGraph, replay == eager bit for bit."""
+    from audioset_convnext_inf_amd import synth
+    wav = synth.synth_waveforms(3, 48000, seed=19).cuda()
+    eager = model16(wav)["clipwise_logits"].clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        model16(wav)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            out = model16(wav)["clipwise_logits"]
+    torch.cuda.synchronize()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+
+
 def test_precision_switch_rebuilds_context(synth_sd):
     m = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
                       use_speed_perturb=False)
