@@ -7,8 +7,11 @@
 //     phase 1   X^T[32 hidden x 32 px] = W1c[32 x C] . LN(y)^T[C x 32 px]     3 C/16 MFMAs; B operand = the wave's
 //               normalised activations (x 2^11) as hi/lo halves, resident in C/2 VGPRs: lane (px, h) holds
 //               channels 16s + 8h .. +7 of k-step s
-//     GELU      on the 16 accumulator registers (bias pre-loaded as the initial accumulator), x 2^4, split into
-//               hi/lo halves -- packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32), 13.5 VALU per element
+//     GELU      on the 16 accumulator registers (bias pre-loaded as the initial accumulator), x 2^h, split into
+//               hi/lo halves -- SCALAR fp32 math, 15 VALU per element (split_math.h, gelu_micro2).  The file is built
+//               with -fno-slp-vectorize: beside MFMAs a packed-FP32 instruction costs far more than the two scalar
+//               ones it replaces (round 2 ran this kernel on v_pk_fma_f32 / v_pk_mul_f32: 104 of them per 36 MFMAs,
+//               0.25 of the matrix peak)
 //     phase 2   out^T[C x 32 px] += W2c[C x 32 hidden] . G                      3 C/16 MFMAs.  Lane (px, h) holds hidden
 //               units 4h + 8q + e (accumulator register 4q + e); registers 8s'..8s'+7 are used as-is for k-step s',
 //               i.e. MFMA k-slot (s', h, j) contracts hidden unit 16 s' + 4h + 8 (j>>2) + (j&3) -- W2c is stored
@@ -18,9 +21,9 @@
 //
 // Schedule (per wave, iteration j over the 4C/32 hidden chunks) -- three independent instruction streams:
 //     matrix  A: phase 1 of chunk j+2 (chained on one accumulator)       B: phase 2 of chunk j
-//     vector  GELU + split of chunk j+1, cut into 24 pieces (8 register pairs x 3 sub-steps of ~9 instructions)
-//             that are dealt over the (k-step | out-tile) units of A and B: each unit is 3 MFMAs = 96 matrix cycles
-//             of which 72 are free for vector issue
+//     vector  GELU + split of chunk j+1, cut into 64 micro-steps (8 register pairs x 8 steps of 2-6 instructions, two
+//             pairs in flight so that consecutive micro-steps are independent) dealt one or two behind EACH MFMA of A
+//             and B, behind scheduling fences
 //     LDS     fragments of unit u+1 are read while unit u multiplies (two named register pairs)
 //     DMA     [W1c | W2c] images run kLead iterations ahead in rings of kLead+1 slots; the end-of-iteration wait is
 //             a counted s_waitcnt vmcnt(N) + bare s_barrier so that the youngest images stay in flight (a
@@ -175,41 +178,56 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
     const int w1row = l31 * (4 * C);
     const int sw2 = (l31 >> 1) & 7;
     const int w2row = l31 * 128;
-    GeluConsts gk;
-    gk.ps = 0.3275911f * 0.70710678f * sinv1;
-    gk.cq = 0.84932180f * sinv1;       // sqrt(log2(e) / 2): exp(-v^2 / 2) = exp2(-(cq a)^2)
-    gk.ca = -0.5f * sinv1 * hscale;
-    gk.cb = sinv1 * hscale;
+    const GeluK2 gk = gelu_k2(sinv1, hscale);
 
 #define ACX_H8(v_) __builtin_bit_cast(h8, v_)
 #define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
     // phase-1 unit = k-step s_: two fragment reads, three MFMAs chained on Xacc
 #define ACX_W1_RD(w1p_, s_, pl_) (*reinterpret_cast<const f32x4*>((w1p_) + w1row + (((2 * (2 * (s_) + hh) + (pl_)) ^ sw1) << 4)))
-#define ACX_P1_MFMA(Xacc, s_, ah_, al_)                                                                         \
+    // MFMA number m_ of an iteration (kTot of them) is followed, behind scheduling fences, by its share of the 64 GELU
+    // micro-steps the iteration carries: steps [64 m / kTot, 64 (m + 1) / kTot)
+#define ACX_AFTER(m_) ACX_FENCE if constexpr (HV) { ACX_MICRO(64 * (m_) / kTot, 64 * ((m_) + 1) / kTot) } ACX_FENCE
+#define ACX_P1_MFMA(Xacc, s_, ah_, al_, m0_)                                                                    \
+        Xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[s_]), Xacc, 0, 0, 0);            \
+        ACX_AFTER((m0_) + 0)                                                                                    \
+        Xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(actl[s_]), Xacc, 0, 0, 0);            \
+        ACX_AFTER((m0_) + 1)                                                                                    \
+        Xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(acth[s_]), Xacc, 0, 0, 0);            \
+        ACX_AFTER((m0_) + 2)
+#define ACX_P1_MFMA_PLAIN(Xacc, s_, ah_, al_)                                                                   \
         Xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[s_]), Xacc, 0, 0, 0);            \
         Xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(actl[s_]), Xacc, 0, 0, 0);            \
         Xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(acth[s_]), Xacc, 0, 0, 0);
     // phase-2 unit i = (tile t = i >> 1, k-step s' = i & 1): fragments of block b = 2s' + hh, hi chunk 2b, lo chunk 2b+1
 #define ACX_W2_RD(w2p_, i_, pl_) (*reinterpret_cast<const f32x4*>((w2p_) + ((i_) >> 1) * 4096 + (((2 * (2 * ((i_) & 1) + hh) + (pl_)) ^ sw2) << 4)))
-#define ACX_P2_MFMA(i_, ah_, al_)                                                                               \
+#define ACX_P2_MFMA(i_, ah_, al_, m0_)                                                                          \
         acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
+        ACX_AFTER((m0_) + 0)                                                                                    \
         acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gl[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
-        acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0);
+        ACX_AFTER((m0_) + 1)                                                                                    \
+        acc[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[(i_) & 1]), acc[(i_) >> 1], 0, 0, 0); \
+        ACX_AFTER((m0_) + 2)
 #define ACX_TOUCH2(h_, l_) { asm volatile("" :: "v"(h_)); asm volatile("" :: "v"(l_)); }
 #define ACX_BIAS_INIT(Xacc, j_)                                                                                 \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
             const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j_) + 8 * q + 4 * hh);                 \
             Xacc[4 * q + 0] = bq[0]; Xacc[4 * q + 1] = bq[1]; Xacc[4 * q + 2] = bq[2]; Xacc[4 * q + 3] = bq[3]; \
         }
-    // GELU pieces [first, first + count) of the 24 that turn Xv into the packed halves uh/ul
-#define ACX_PIECES(first_, count_)                                                                              \
-        _Pragma("unroll") for (int pc_ = (first_); pc_ < (first_) + (count_); ++pc_) {                          \
-            const int pr_ = pc_ / 3, sub_ = pc_ - 3 * pr_;                                                      \
-            f32x2 a2_;                                                                                          \
-            a2_.x = Xv[2 * pr_]; a2_.y = Xv[2 * pr_ + 1];                                                       \
-            if (sub_ == 0) gelu_piece1(a2_, gk, s_av[pr_], s_t[pr_], s_e[pr_]);                                 \
-            else if (sub_ == 1) gelu_piece2(a2_, s_av[pr_], s_t[pr_], s_e[pr_], gk, s_g[pr_]);                  \
-            else gelu_piece3(s_g[pr_], uh[pr_], ul[pr_]);                                                       \
+    // GELU micro-steps [from, to) of the 64 that turn Xv into the packed halves uh / ul: step m works on register pair
+    // 2 (m / 16) + (m & 1) -- two pairs alternate, so neighbouring micro-steps do not depend on each other -- and is
+    // step (m % 16) / 2 of that pair's eight
+#define ACX_MICRO(from_, to_)                                                                                   \
+        _Pragma("unroll") for (int mm_ = (from_); mm_ < (to_); ++mm_) {                                         \
+            const int pr_ = 2 * (mm_ / 16) + (mm_ & 1), st_ = (mm_ % 16) >> 1;                                  \
+            GeluState2& gs_ = (mm_ & 1) ? gsB : gsA;                                                            \
+            if (st_ == 0) { gs_.ax = Xv[2 * pr_]; gs_.ay = Xv[2 * pr_ + 1]; gelu_micro2<0>(gs_, gk, uh[pr_], ul[pr_]); } \
+            else if (st_ == 1) gelu_micro2<1>(gs_, gk, uh[pr_], ul[pr_]);                                       \
+            else if (st_ == 2) gelu_micro2<2>(gs_, gk, uh[pr_], ul[pr_]);                                       \
+            else if (st_ == 3) gelu_micro2<3>(gs_, gk, uh[pr_], ul[pr_]);                                       \
+            else if (st_ == 4) gelu_micro2<4>(gs_, gk, uh[pr_], ul[pr_]);                                       \
+            else if (st_ == 5) gelu_micro2<5>(gs_, gk, uh[pr_], ul[pr_]);                                       \
+            else if (st_ == 6) gelu_micro2<6>(gs_, gk, uh[pr_], ul[pr_]);                                       \
+            else gelu_micro2<7>(gs_, gk, uh[pr_], ul[pr_]);                                                     \
         }
 #define ACX_PACK_G(dh_, dl_)                                                                                    \
         dh_[0] = __builtin_bit_cast(f32x4, uint4{uh[0], uh[1], uh[2], uh[3]});                                  \
@@ -220,22 +238,22 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
     __syncthreads();      // W1c(0..1+L), W2c(0..L-1) landed (hipcc drains the LDS-DMA before the barrier); b1s visible
     f32x16 Xv, Xnn;       // Xv: pre-activation of chunk j+1 (GELU input of iteration j); Xnn: chunk j+2, accumulating
     f32x4 gh[2], gl[2];   // G(j): B operand of phase 2, two k-steps, hi / lo halves
-    f32x2 s_av[8], s_t[8], s_e[8], s_g[8];
+    GeluState2 gsA, gsB;
     unsigned uh[8], ul[8];
     {   // prologue: X(0) -> G(0), X(1) -> Xv; nothing to overlap with yet
         ACX_BIAS_INIT(Xv, 0)
 #pragma unroll
         for (int s = 0; s < Cfg::kSteps; ++s) {
             const f32x4 ah = ACX_W1_RD(w1buf, s, 0), al = ACX_W1_RD(w1buf, s, 1);
-            ACX_P1_MFMA(Xv, s, ah, al)
+            ACX_P1_MFMA_PLAIN(Xv, s, ah, al)
         }
-        ACX_PIECES(0, 24)
+        ACX_MICRO(0, 64)
         ACX_PACK_G(gh, gl)
         ACX_BIAS_INIT(Xv, 1)
 #pragma unroll
         for (int s = 0; s < Cfg::kSteps; ++s) {
             const f32x4 ah = ACX_W1_RD(w1buf + Cfg::kHalfBytes, s, 0), al = ACX_W1_RD(w1buf + Cfg::kHalfBytes, s, 1);
-            ACX_P1_MFMA(Xv, s, ah, al)
+            ACX_P1_MFMA_PLAIN(Xv, s, ah, al)
         }
     }
     __syncthreads();      // every wave is done with W1 ring slots 0 and 1 before they are refilled
@@ -246,8 +264,7 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
     auto body = [&](auto has_a, auto has_v, const int j) __attribute__((always_inline)) {
         constexpr bool HA = decltype(has_a)::value, HV = decltype(has_v)::value;
         constexpr int kRegions = (HA ? Cfg::kSteps : 0) + Cfg::kUnits;
-        constexpr int kPer = HV ? 24 / kRegions : 0;           // GELU pieces per unit (24 divides evenly: 12, 24 or 6 units)
-        static_assert(!HV || kPer * kRegions == 24, "GELU pieces must divide over the units");
+        constexpr int kTot = 3 * kRegions;                     // MFMAs of this iteration
         // this iteration's DMA pieces (W1c(j+2+L) then W2c(j+L)) are threaded through the units, one every
         // kRegions / (2 kPieces) units: issued in a burst each piece costs 100-185 cycles of issue
         constexpr int kPerWave = (RS ? 1 : 2) * Cfg::kPieces;      // pieces a wave issues per iteration
@@ -277,16 +294,14 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
             for (int s = 0; s < Cfg::kSteps; s += 2) {
                 a1h = ACX_W1_RD(w1p, s + 1, 0); a1l = ACX_W1_RD(w1p, s + 1, 1);
                 ACX_FENCE
-                ACX_P1_MFMA(Xnn, s, a0h, a0l)
+                ACX_P1_MFMA(Xnn, s, a0h, a0l, 3 * (s))
                 ACX_DMA_AT(s)
-                ACX_PIECES(kPer * (s), kPer)
                 ACX_FENCE
                 ACX_TOUCH2(a1h, a1l)
                 if (s + 2 < Cfg::kSteps) { a0h = ACX_W1_RD(w1p, s + 2, 0); a0l = ACX_W1_RD(w1p, s + 2, 1); }
                 ACX_FENCE
-                ACX_P1_MFMA(Xnn, s + 1, a1h, a1l)
+                ACX_P1_MFMA(Xnn, s + 1, a1h, a1l, 3 * (s + 1))
                 ACX_DMA_AT(s + 1)
-                ACX_PIECES(kPer * (s + 1), kPer)
                 ACX_FENCE
                 if (s + 2 < Cfg::kSteps) ACX_TOUCH2(a0h, a0l)
             }
@@ -300,16 +315,14 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
             for (int i = 0; i < Cfg::kUnits; i += 2) {
                 a1h = ACX_W2_RD(w2p, i + 1, 0); a1l = ACX_W2_RD(w2p, i + 1, 1);
                 ACX_FENCE
-                ACX_P2_MFMA(i, a0h, a0l)
+                ACX_P2_MFMA(i, a0h, a0l, 3 * (r0 + i))
                 ACX_DMA_AT(r0 + i)
-                ACX_PIECES(kPer * (r0 + i), kPer)
                 ACX_FENCE
                 ACX_TOUCH2(a1h, a1l)
                 if (i + 2 < Cfg::kUnits) { a0h = ACX_W2_RD(w2p, i + 2, 0); a0l = ACX_W2_RD(w2p, i + 2, 1); }
                 ACX_FENCE
-                ACX_P2_MFMA(i + 1, a1h, a1l)
+                ACX_P2_MFMA(i + 1, a1h, a1l, 3 * (r0 + i + 1))
                 ACX_DMA_AT(r0 + i + 1)
-                ACX_PIECES(kPer * (r0 + i + 1), kPer)
                 ACX_FENCE
                 if (i + 2 < Cfg::kUnits) ACX_TOUCH2(a0h, a0l)
             }
@@ -338,11 +351,13 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
 #undef ACX_FENCE
 #undef ACX_W1_RD
 #undef ACX_P1_MFMA
+#undef ACX_P1_MFMA_PLAIN
+#undef ACX_AFTER
 #undef ACX_W2_RD
 #undef ACX_P2_MFMA
 #undef ACX_TOUCH2
 #undef ACX_BIAS_INIT
-#undef ACX_PIECES
+#undef ACX_MICRO
 #undef ACX_PACK_G
 
     // ---- epilogue: lane (px, hh), tile t, q: channels 32t + 8q + 4hh .. +3  ->  x = x + out + b2 ---------

@@ -12,7 +12,7 @@
 //               LDS holds a ring of three segments: one being multiplied, one landed or landing, one being requested.
 //   schedule    segment 2k-1: phase 1 of chunk k    X^T[32 hidden x 32 px] = W1c . LN(y)^T     3 C/16 MFMAs on Xn
 //               segment 2k  : phase 2 of chunk k-1  out^T[C x 32 px] += W2c . G(k-1)            3 C/16 MFMAs
-//               GELU + hi/lo split of X(k) -> G(k): 72 micro-steps of ~6 vector instructions, the first half dealt over
+//               GELU + hi/lo split of X(k) -> G(k): 64 micro-steps of 2-6 vector instructions, the first half dealt over
 //               the MFMAs of segment 2k, the second half over those of segment 2k+1 -- one wave per SIMD issues both
 //               streams, and only ~24 cycles of vector issue hide behind an MFMA (MI355X_MICROARCH.md, cycle constants):
 //               measured, all of the GELU inside the phase-2 segment cost 73 of 219 us per tile (tools/run_wide_lab.sh).
@@ -43,8 +43,8 @@ struct WideCfg {
     static constexpr int kUnits = 2 * (C / 32);             // units of a phase-2 segment (out tile, k-step)
     static constexpr size_t kLdsBytes = 3 * (size_t)kSegBytes + 4 * C * 4;
     static constexpr int kMfmas = 3 * kUnits * PT;          // MFMAs per segment
-    static constexpr int kHalf = 36 * PT;                   // GELU micro-steps a segment carries (half of the 72 per pixel tile)
-    static_assert(C % 32 == 0 && kSteps == kUnits && kUnits % kPieces == 0 && (kHalf % kMfmas == 0 || kMfmas % kHalf == 0), "unit / piece bookkeeping");
+    static constexpr int kHalf = 32 * PT;                   // GELU micro-steps a segment carries (half of the 64 per pixel tile)
+    static_assert(C % 32 == 0 && kSteps == kUnits && kUnits % kPieces == 0, "unit / piece bookkeeping");
     // W1 rows are 4 C bytes: the XOR that spreads 16 consecutive rows over the LDS banks (api.hip packs the image with it)
     __device__ static int swz1(int row) { return (C % 64 == 0) ? (row & 15) : ((row >> 1) & 7); }
 };
@@ -153,11 +153,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) w2off[sp][pl] = l31 * 128 + (((2 * (2 * sp + hh) + pl) ^ ((l31 >> 1) & 7)) << 4);
-    GeluConsts gk;
-    gk.ps = 0.3275911f * 0.70710678f * sinv1;
-    gk.cq = 0.84932180f * sinv1;       // sqrt(log2(e) / 2): exp(-v^2 / 2) = exp2(-(cq a)^2)
-    gk.ca = -0.5f * sinv1 * hscale;
-    gk.cb = sinv1 * hscale;
+    const GeluK2 gk = gelu_k2(sinv1, hscale);
 
 #define ACX_H8(v_) __builtin_bit_cast(h8, v_)
 #define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
@@ -191,21 +187,23 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
             acc[pt_][(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[pt_][(i_) & 1]), acc[pt_][(i_) >> 1], 0, 0, 0); \
             ACX_AFTER_MFMA(HV, 0, (3 * (i_) + 2) * PT + pt_) }
-    // micro-steps [from, to) of the kHalf that segment half half_ carries: step sg_ belongs to pixel tile sg_ / 36 and is
-    // step 36 half_ + sg_ % 36 of the 72 (8 register pairs x 9 steps) that turn that tile's Xv into its uh / ul
+    // micro-steps [from, to) of the kHalf that segment half half_ carries: step sg_ belongs to pixel tile sg_ / 32 and is
+    // step 32 half_ + sg_ % 32 of the 64 (8 register pairs x 8 steps, split_math.h gelu_micro2) that turn that tile's Xv
+    // into its uh / ul; two pairs alternate (pair 2 (m / 16) + (m & 1), step (m % 16) / 2) so that consecutive micro-steps
+    // are independent
 #define ACX_MICRO_RANGE(half_, from_, to_)                                                                      \
         _Pragma("unroll") for (int sg_ = (from_); sg_ < (to_); ++sg_) {                                         \
-            const int mt_ = sg_ / 36, mm_ = 36 * (half_) + sg_ % 36;                                            \
-            const int pr_ = mm_ / 9, st_ = mm_ - 9 * pr_;                                                       \
-            if (st_ == 0) { gs.ax = Xv[mt_][2 * pr_]; gs.ay = Xv[mt_][2 * pr_ + 1]; gelu_micro<0>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]); } \
-            else if (st_ == 1) gelu_micro<1>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
-            else if (st_ == 2) gelu_micro<2>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
-            else if (st_ == 3) gelu_micro<3>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
-            else if (st_ == 4) gelu_micro<4>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
-            else if (st_ == 5) gelu_micro<5>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
-            else if (st_ == 6) gelu_micro<6>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
-            else if (st_ == 7) gelu_micro<7>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                               \
-            else gelu_micro<8>(gs, gk, uh[mt_][pr_], ul[mt_][pr_]);                                             \
+            const int mt_ = sg_ / 32, mm_ = 32 * (half_) + sg_ % 32;                                            \
+            const int pr_ = 2 * (mm_ / 16) + (mm_ & 1), st_ = (mm_ % 16) >> 1;                                  \
+            GeluState2& gs_ = (mm_ & 1) ? gsB : gsA;                                                            \
+            if (st_ == 0) { gs_.ax = Xv[mt_][2 * pr_]; gs_.ay = Xv[mt_][2 * pr_ + 1]; gelu_micro2<0>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]); } \
+            else if (st_ == 1) gelu_micro2<1>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
+            else if (st_ == 2) gelu_micro2<2>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
+            else if (st_ == 3) gelu_micro2<3>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
+            else if (st_ == 4) gelu_micro2<4>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
+            else if (st_ == 5) gelu_micro2<5>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
+            else if (st_ == 6) gelu_micro2<6>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
+            else gelu_micro2<7>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                                           \
         }
 #define ACX_TOUCH2(h_, l_) { asm volatile("" :: "v"(h_)); asm volatile("" :: "v"(l_)); }
 #define ACX_BIAS_INIT(j_)                                                                                       \
@@ -233,7 +231,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     f32x4 gh[PT][2], gl[PT][2];   // G(k - 1): B operand of phase 2, two k-steps, hi / lo halves
     unsigned uh[PT][8], ul[PT][8];
     constexpr int kDmaStride = Cfg::kUnits / Cfg::kPieces;       // one piece every kDmaStride units
-    GeluState gs;
+    GeluState2 gsA, gsB;
 
     // one phase-1 segment: X = b1 + W1c . LN(y)^T for chunk k_, image in ring slot grp_, requesting segment seg_ + 2
     auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {

@@ -97,4 +97,64 @@ __device__ __forceinline__ void gelu_micro(GeluState& s, const GeluConsts k, uns
     }
 }
 
+
+// ---- GELU + split, second form (round 3): 15 vector instructions per element instead of 17-19 -------------------------
+//   gelu(v) kH = 0.5 kH v + |v| kH (0.5 - 0.5 q(|v|)),   q = erfc(|v| / sqrt 2) = poly(t) t exp(-v^2 / 2)   (A&S 7.1.26)
+// With a = v / sinv (the accumulator's unit) and hb = 0.5 sinv kH:   g = fma(|a|, r, a hb),   r = fma(P, e, hb),
+// P = t (K1' + t (K2' + ...)),  K' = -hb K  -- the factors -0.5, sinv and kH ride in the polynomial's coefficients (five
+// scalars per launch), the positive part costs no v_max, and the fp32 -> fp16 hi / lo split is v_cvt_pk_f16_f32 +
+// v_fma_mix_f32 (g - float(hi) in ONE instruction per element, straight from the packed hi halves) + v_cvt_pk_f16_f32.
+// For v << 0 the two terms cancel: exactly when q has underflowed (r == hb), and otherwise with an absolute error of
+// |v| kH 2^-25 -- what the reference's own fp32 evaluation of 0.5 v (1 + erf) carries there.
+// EIGHT micro-steps of 2-6 instructions per register pair (two values); the state of a pair lives across its steps.
+struct GeluK2 { float ps, cq, hb, k1, k2, k3, k4, k5; };
+__device__ __forceinline__ GeluK2 gelu_k2(float sinv, float kh) {
+    GeluK2 k;
+    k.ps = 0.3275911f * 0.70710678f * sinv;
+    k.cq = 0.84932180f * sinv;          // sqrt(log2(e) / 2): exp(-v^2 / 2) = exp2(-(cq a)^2)
+    k.hb = 0.5f * sinv * kh;            // a power of two times 0.5: the products below are exact scalings
+    k.k1 = -k.hb * 0.254829592f; k.k2 = -k.hb * -0.284496736f; k.k3 = -k.hb * 1.421413741f;
+    k.k4 = -k.hb * -1.453152027f; k.k5 = -k.hb * 1.061405429f;
+    return k;
+}
+struct GeluState2 { float ax, ay, tx, ty, ex, ey, px, py; };
+__device__ __forceinline__ float acx_sub_hi_half(float g, unsigned h, const bool upper) {      // g - float(half of h)
+    float r;
+    if (upper) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(g), "v"(h));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(g), "v"(h));
+    return r;
+}
+template <int STEP>
+__device__ __forceinline__ void gelu_micro2(GeluState2& s, const GeluK2 k, unsigned& hi, unsigned& lo) {
+    if constexpr (STEP == 0) {
+        s.tx = __builtin_fmaf(__builtin_fabsf(s.ax), k.ps, 1.0f);                 // den
+        s.ty = __builtin_fmaf(__builtin_fabsf(s.ay), k.ps, 1.0f);
+    } else if constexpr (STEP == 1) {
+        s.tx = __builtin_amdgcn_rcpf(s.tx); s.ty = __builtin_amdgcn_rcpf(s.ty);
+        s.ex = s.ax * k.cq; s.ey = s.ay * k.cq;                                   // u (scaled first: a * a alone may overflow)
+    } else if constexpr (STEP == 2) {
+        s.ex = __builtin_amdgcn_exp2f(-(s.ex * s.ex)); s.ey = __builtin_amdgcn_exp2f(-(s.ey * s.ey));
+    } else if constexpr (STEP == 3) {
+        s.px = __builtin_fmaf(s.tx, k.k5, k.k4); s.py = __builtin_fmaf(s.ty, k.k5, k.k4);
+        s.px = __builtin_fmaf(s.px, s.tx, k.k3); s.py = __builtin_fmaf(s.py, s.ty, k.k3);
+    } else if constexpr (STEP == 4) {
+        s.px = __builtin_fmaf(s.px, s.tx, k.k2); s.py = __builtin_fmaf(s.py, s.ty, k.k2);
+        s.px = __builtin_fmaf(s.px, s.tx, k.k1); s.py = __builtin_fmaf(s.py, s.ty, k.k1);
+        s.px *= s.tx; s.py *= s.ty;                                               // -hb poly(t) t
+    } else if constexpr (STEP == 5) {
+        s.px = __builtin_fmaf(s.px, s.ex, k.hb); s.py = __builtin_fmaf(s.py, s.ey, k.hb);     // r = hb (1 - q)
+        s.tx = s.ax * k.hb; s.ty = s.ay * k.hb;                                   // 0.5 v kH
+    } else if constexpr (STEP == 6) {
+        // no clamp to the fp16 range: acx_finalize bounds |h| and picks the hidden scale so that it cannot be exceeded
+        // (api.hip, hidden_scale_for); were it ever exceeded the result would be inf / NaN -- loud, not silently saturated
+        s.ex = __builtin_fmaf(__builtin_fabsf(s.ax), s.px, s.tx);                 // g
+        s.ey = __builtin_fmaf(__builtin_fabsf(s.ay), s.py, s.ty);
+        f32x2 g; g.x = s.ex; g.y = s.ey;
+        hi = __builtin_bit_cast(unsigned, __builtin_convertvector(g, h2));
+    } else {
+        f32x2 r; r.x = acx_sub_hi_half(s.ex, hi, false); r.y = acx_sub_hi_half(s.ey, hi, true);
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
+    }
+}
+
 }  // namespace acx

@@ -1,55 +1,60 @@
 #!/usr/bin/env python
 """Build-time check of the CU-exclusive launch contract (acx_internal.h): every kernel that runs dense
-16-bit MFMA (gemm_split_kernel, mlp_fused_split_kernel, gemm_bf16_kernel) must be emitted with a register allocation
-that fills the SIMD -- 256 registers per lane for 512-thread workgroups, 512 for 256-thread ones.
-Compiles the sources to device assembly (no GPU needed) and reads the kernel descriptors.
-    python tools/check_exclusive.py            exit code 0 = contract holds"""
+16-bit MFMA (gemm_split_kernel, mlp_fused_split_kernel, mlp_fused_wide*_kernel, gemm_bf16_kernel, ...) must ship with a
+register allocation that fills the SIMD -- 256 registers per lane for 512-thread workgroups, 512 for 256-thread ones.
+
+Reads the kernel metadata of the code objects INSIDE the built libacx.so (llvm-objdump --offloading + llvm-readelf
+--notes): what is checked is what ships, whatever flags or toolchain built it.  No GPU needed.
+    python tools/check_exclusive.py [path/to/libacx.so]            exit code 0 = contract holds"""
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CS = os.path.join(ROOT, "audioset-convnext-inf_amd", "csrc")
-# every __global__ of these files runs dense 16-bit MFMA
-SOURCES = ["gemm_split.hip", "mlp_fused_split.hip", "mlp_fused_wide.hip", "mlp_fused_wide_bf16.hip", "gemm_bf16.hip"]
+LLVM = os.environ.get("ACX_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+# kernels (namespace acx) that run dense 16-bit MFMA on live data
+EXCLUSIVE = ("gemm_split_kernel", "mlp_fused_split_kernel", "mlp_fused_wide_kernel", "mlp_fused_wide_bf16_kernel",
+             "mlp_fused_stat_bf16_kernel", "gemm_bf16_kernel")
 
 
-def descriptors(path):
+def kernels_of(lib):
+    """[(mangled name, threads, vgpr_count incl. AGPRs, scratch bytes)] of every gfx950 kernel inside lib"""
+    out = []
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-w", "-DACX_BUILD",
-                               "--cuda-device-only", "-S", path, "-o", out] + (["-fno-slp-vectorize"] if "mlp_fused_wide" in path else []))
-        text = open(out).read()
-    res = {}
-    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
-        body = m.group(2)
-        get = lambda k: int(re.search(r"\.amdhsa_%s (\d+)" % k, body).group(1))
-        res[m.group(1)] = {"vgpr": get("next_free_vgpr"), "scratch": get("private_segment_fixed_size")}
-    threads = {}
-    meta = text[text.index("amdhsa.kernels:"):] if "amdhsa.kernels:" in text else ""
-    for entry in re.split(r"\n  - ", meta)[1:]:
-        n = re.search(r"\.name:\s+(\S+)", entry)
-        t = re.search(r"\.max_flat_workgroup_size:\s+(\d+)", entry)
-        if n and t:
-            threads[n.group(1)] = int(t.group(1))
-    return res, threads
+        shutil.copy(lib, os.path.join(d, "lib.so"))
+        subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=d, stdout=subprocess.DEVNULL)
+        for f in sorted(os.listdir(d)):
+            if "amdgcn" not in f:
+                continue
+            notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", f], cwd=d, text=True)
+            for entry in re.split(r"\n\s+- \.", notes)[1:]:
+                name = re.search(r"\.name:\s+(\S+)", entry)
+                if not name or ".vgpr_count" not in entry:
+                    continue
+                get = lambda k: int(re.search(r"%s:\s+(\d+)" % re.escape(k), entry).group(1))
+                out.append((name.group(1), get("max_flat_workgroup_size"), get(".vgpr_count"), get("private_segment_fixed_size")))
+    return out
 
 
 def main():
-    bad = 0
-    for src in SOURCES:
-        path = os.path.join(CS, src)
-        if not os.path.isfile(path):
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "audioset-convnext-inf_amd", "libacx.so")
+    ks = kernels_of(lib)
+    bad = seen = 0
+    for name, threads, vgpr, scratch in sorted(ks):
+        m = re.match(r"_ZN3acx\d+([A-Za-z0-9_]+?)I", name)          # acx::<kernel><template args>
+        if not m or m.group(1) not in EXCLUSIVE:
             continue
-        desc, threads = descriptors(path)
-        for name, d in sorted(desc.items()):
-            t = threads.get(name, 0)
-            want = 256 if t == 512 else 512 if t == 256 else -1
-            ok = d["vgpr"] == want          # scratch (a few spilled dwords outside the loops) is reported, not an error
-            bad += not ok
-            print("%s %-90s threads %4d registers %3d (want %3d) scratch %d" % ("ok " if ok else "BAD", name[:90], t, d["vgpr"], want, d["scratch"]))
+        seen += 1
+        want = 256 if threads == 512 else 512 if threads == 256 else -1
+        ok = vgpr == want          # scratch (a few spilled dwords outside the loops) is reported, not an error
+        bad += not ok
+        print("%s %-100s threads %4d registers %3d (want %3d) scratch %d" % ("ok " if ok else "BAD", name[:100], threads, vgpr, want, scratch))
+    if seen < 10:
+        print("BAD only %d CU-exclusive kernels found in %s" % (seen, lib))
+        bad += 1
     return 1 if bad else 0
 
 
