@@ -722,11 +722,16 @@ static int forward_one(acx_ctx* c, const float* wav, int B, int64_t L, int mode,
     ACX_TRY(launch_logmel(c, wav, B, L, p.T, feat, true, st));
     ACX_TRY(launch_stem(c, feat, B, p.T, p.Hs[0], x[0], st));
     for (int s = 0; s < 4; ++s) {
-        if (s > 0) ACX_TRY(run_downsample(c, s, x[s - 1], x[s], y, B, p.Hs[s - 1], p.Ws[s - 1], st, block_can_emit_ln(c, s - 1)));
+        // The last block of stages 0-2 writes LayerNorm(x) as GEMM operand rows (S16 / bf16) instead of x: nothing else
+        // reads that x (convnext.py:270-273).  The rows go to the `hidden` scratch (idle in the fused stages), never to
+        // y: the block kernel reads y -- with a tile of look-ahead -- while it writes them, and bf16 rows are shorter
+        // than the fp32 rows they would overwrite.
+        if (s > 0) {
+            const bool have_ln = block_can_emit_ln(c, s - 1);
+            ACX_TRY(run_downsample(c, s, x[s - 1], x[s], have_ln ? hidden : y, B, p.Hs[s - 1], p.Ws[s - 1], st, have_ln));
+        }
         for (int j = 0; j < kDepths[s]; ++j) {
-            // the last block of stages 0-2 writes LayerNorm(x) in S16 form into y (the downsample's operand buffer)
-            // instead of x: nothing else reads that x (convnext.py:270-273)
-            void* ln_out = (j == kDepths[s] - 1 && block_can_emit_ln(c, s)) ? (void*)y : nullptr;
+            void* ln_out = (j == kDepths[s] - 1 && block_can_emit_ln(c, s)) ? (void*)hidden : nullptr;
             ACX_TRY(run_block(c, s, j, x[s], y, hidden, stats, B, p.Hs[s], p.Ws[s], st, ln_out));
         }
     }

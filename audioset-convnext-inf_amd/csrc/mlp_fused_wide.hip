@@ -26,6 +26,28 @@
 
 namespace acx {
 
+// Diagnostic builds only (-DACX_FW_STAMPS; tools/lab): s_memtime differences per section, summed per wave.  The product
+// build contains no stamp.
+#ifdef ACX_FW_STAMPS
+__device__ unsigned long long acx_fw_stamps[2048 * 4 * 8];
+#define ACX_WSTAMP_DECL unsigned long long st_prev_ = 0, st_sum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ACX_WSTAMP(k_)                                                                                          \
+    {                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        unsigned long long t_;                                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                            \
+        if ((k_) >= 0) st_sum_[(k_) < 0 ? 0 : (k_)] += t_ - st_prev_;                                           \
+        st_prev_ = t_;                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    }
+#define ACX_WSTAMP_FLUSH                                                                                        \
+    if (lane == 0 && blockIdx.x < 2048) { _Pragma("unroll") for (int k = 0; k < 8; ++k) acx_fw_stamps[(blockIdx.x * 4 + wave) * 8 + k] = st_sum_[k]; }
+#else
+#define ACX_WSTAMP_DECL
+#define ACX_WSTAMP(k_)
+#define ACX_WSTAMP_FLUSH
+#endif
+
 // PT = pixel tiles (of 32) per wave: every weight fragment read from LDS feeds PT x 3 MFMAs.  Shipped with PT = 1.
 // Measured for C = 96 (stage 0), where a segment is only 18 MFMAs per pixel tile against the fixed cost of a segment
 // (three LDS-DMA issues, the barrier) and 36 GELU micro-steps: PT = 2 is correct (parity suite green) but runs 647 us per
@@ -43,8 +65,27 @@ struct WideCfg {
     static constexpr int kUnits = 2 * (C / 32);             // units of a phase-2 segment (out tile, k-step)
     static constexpr size_t kLdsBytes = 3 * (size_t)kSegBytes + 4 * C * 4;
     static constexpr int kMfmas = 3 * kUnits * PT;          // MFMAs per segment
-    static constexpr int kHalf = 32 * PT;                   // GELU micro-steps a segment carries (half of the 64 per pixel tile)
+    static constexpr int kDmaStride = kUnits / kPieces;     // one LDS-DMA piece every kDmaStride units
+    // GELU nano-steps (single instructions, split_math.h) a segment carries: half of a pixel tile's 8 register pairs
+    static constexpr int kNano = 4 * kGeluNano * PT;
     static_assert(C % 32 == 0 && kSteps == kUnits && kUnits % kPieces == 0, "unit / piece bookkeeping");
+    // Issue budget of the gap BEHIND MFMA m of a segment (unit m / 3 / PT, position m % 3 for PT = 1).  A gap hides about
+    // five single-issue instructions (profiles/r03_a_coissue_table.txt); the fixed tenants are the LDS-DMA piece (s_mov m0,
+    // s_nop, the load: behind the FIRST MFMA of every kDmaStride-th unit) and the counted wait + two fragment reads (behind
+    // the LAST MFMA of every unit).  What is left of four slots per gap is dealt to the GELU in proportion.
+    // (closed forms, no loops: the arguments become constants only after the unit loops are unrolled, and everything derived
+    // from them -- register indices above all -- must fold then)
+    __host__ __device__ static constexpr int cum_free_units(int u) { return 9 * u - 3 * ((u + kDmaStride - 1) / kDmaStride); }   // gaps of units [0, u)
+    __host__ __device__ static constexpr int cum_free(int m) {       // free slots of gaps [0, m]
+        const int g = m / PT, u = g / 3, pos = g % 3;
+        const int f0 = (u % kDmaStride == 0) ? 1 : 4;
+        return PT * (cum_free_units(u) + (pos == 0 ? f0 : (pos == 1 ? f0 + 4 : f0 + 5)));
+    }
+    __host__ __device__ static constexpr int nano_end(int m) {      // nano-steps issued once the gap behind MFMA m is done
+        constexpr int tot = PT * cum_free_units(kUnits);
+        return (kNano * cum_free(m) + tot / 2) / tot;
+    }
+    __host__ __device__ static constexpr int nano_begin(int m) { return m == 0 ? 0 : nano_end(m - 1); }
     // W1 rows are 4 C bytes: the XOR that spreads 16 consecutive rows over the LDS banks (api.hip packs the image with it)
     __device__ static int swz1(int row) { return (C % 64 == 0) ? (row & 15) : ((row >> 1) & 7); }
 };
@@ -66,6 +107,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     const int l31 = lane & 31, hh = lane >> 5;
     ACX_CLAIM_VGPR(255);          // CU-exclusive: one wave per SIMD holds the SIMD's whole register file
     ACX_CLAIM_AGPR(255);
+    ACX_WSTAMP_DECL
+    ACX_WSTAMP(-1)
     long long mrow[PT];           // this lane's pixel row in each of the wave's pixel tiles
     bool valid[PT];
 #pragma unroll
@@ -77,10 +120,12 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 
     constexpr int n = Cfg::kChunks;
     const int dma_lane = (wave * Cfg::kPieces) * 1024 + lane * 16;      // this lane's slot in piece 0 of its wave
+    // (issued from inline asm: next to the builtin form hipcc waits lgkmcnt(0) / vmcnt(0) wherever an LDS read follows, which
+    // defeats the two-unit look-ahead of the fragment reads; the counted waits at the segment ends are this file's own)
+    const unsigned smem_a = acx_lds_addr(smem);
 #define ACX_WDMA(seg_, piece_, grp_)                                                                             \
-        __builtin_amdgcn_global_load_lds(                                                                        \
-            (const __attribute__((address_space(1))) void*)(wstream + (long long)(seg_) * Cfg::kSegBytes + dma_lane + (piece_) * 1024), \
-            (__attribute__((address_space(3))) void*)(smem + (grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_)) * 1024), 16, 0, 0);
+        acx_glds16_own_m0(wstream + (long long)(seg_) * Cfg::kSegBytes + dma_lane + (piece_) * 1024,             \
+                          __builtin_amdgcn_readfirstlane(smem_a + (grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_)) * 1024));
     // segments 0 and 1 are requested before anything else; segment s + 2 follows during segment s
 #pragma unroll
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(0, p, 0)
@@ -163,11 +208,12 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     // segment carries: steps [kHalf m / kMfmas, kHalf (m + 1) / kMfmas) of the half (C = 384: one after every other MFMA,
     // C = 192: one after each, C = 96: two after each)
 #define ACX_AFTER_MFMA(HV_, half_, m_)                                                                          \
-        ACX_FENCE if constexpr (HV_) { ACX_MICRO_RANGE(half_, Cfg::kHalf * (m_) / Cfg::kMfmas, Cfg::kHalf * ((m_) + 1) / Cfg::kMfmas) } ACX_FENCE
+        ACX_FENCE if constexpr (HV_) { ACX_NANO_RANGE(half_, Cfg::nano_begin(m_), Cfg::nano_end(m_)) } ACX_FENCE
     // the three terms of a unit, each over the PT pixel tiles (independent accumulators back to back)
 #define ACX_P1_MFMA(s_, ah_, al_)                                                                               \
         _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
             Xn[pt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[pt_][s_]), Xn[pt_], 0, 0, 0); \
+            if (pt_ == 0 && (s_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (s_) / Cfg::kDmaStride, g2) } \
             ACX_AFTER_MFMA(HV, 1, (3 * (s_) + 0) * PT + pt_) }                                                  \
         _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
             Xn[pt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(actl[pt_][s_]), Xn[pt_], 0, 0, 0); \
@@ -180,6 +226,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #define ACX_P2_MFMA(i_, ah_, al_)                                                                               \
         _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
             acc[pt_][(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(gh[pt_][(i_) & 1]), acc[pt_][(i_) >> 1], 0, 0, 0); \
+            if (pt_ == 0 && (i_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (i_) / Cfg::kDmaStride, g2) } \
             ACX_AFTER_MFMA(HV, 0, (3 * (i_) + 0) * PT + pt_) }                                                  \
         _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
             acc[pt_][(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gl[pt_][(i_) & 1]), acc[pt_][(i_) >> 1], 0, 0, 0); \
@@ -187,25 +234,43 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
             acc[pt_][(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[pt_][(i_) & 1]), acc[pt_][(i_) >> 1], 0, 0, 0); \
             ACX_AFTER_MFMA(HV, 0, (3 * (i_) + 2) * PT + pt_) }
-    // micro-steps [from, to) of the kHalf that segment half half_ carries: step sg_ belongs to pixel tile sg_ / 32 and is
-    // step 32 half_ + sg_ % 32 of the 64 (8 register pairs x 8 steps, split_math.h gelu_micro2) that turn that tile's Xv
-    // into its uh / ul; two pairs alternate (pair 2 (m / 16) + (m & 1), step (m % 16) / 2) so that consecutive micro-steps
-    // are independent
-#define ACX_MICRO_RANGE(half_, from_, to_)                                                                      \
-        _Pragma("unroll") for (int sg_ = (from_); sg_ < (to_); ++sg_) {                                         \
-            const int mt_ = sg_ / 32, mm_ = 32 * (half_) + sg_ % 32;                                            \
-            const int pr_ = 2 * (mm_ / 16) + (mm_ & 1), st_ = (mm_ % 16) >> 1;                                  \
-            GeluState2& gs_ = (mm_ & 1) ? gsB : gsA;                                                            \
-            if (st_ == 0) { gs_.ax = Xv[mt_][2 * pr_]; gs_.ay = Xv[mt_][2 * pr_ + 1]; gelu_micro2<0>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]); } \
-            else if (st_ == 1) gelu_micro2<1>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
-            else if (st_ == 2) gelu_micro2<2>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
-            else if (st_ == 3) gelu_micro2<3>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
-            else if (st_ == 4) gelu_micro2<4>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
-            else if (st_ == 5) gelu_micro2<5>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
-            else if (st_ == 6) gelu_micro2<6>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                             \
-            else gelu_micro2<7>(gs_, gk, uh[mt_][pr_], ul[mt_][pr_]);                                           \
+    // nano-steps [from, to) of the kNano that segment half half_ carries: step ng_ belongs to pixel tile ng_ / 120 and is
+    // instruction ng_ % 30 of register pair 4 half_ + (ng_ % 120) / 30 (split_math.h, gelu_nano): pair after pair, in order
+#define ACX_NANO_RANGE(half_, from_, to_)                                                                       \
+        _Pragma("unroll") for (int ng_ = (from_); ng_ < (to_); ++ng_) {                                         \
+            const int mt_ = ng_ / (4 * kGeluNano), pr_ = 4 * (half_) + (ng_ % (4 * kGeluNano)) / kGeluNano, st_ = ng_ % kGeluNano; \
+            if (st_ == 0) { gsA.ax = Xv[mt_][2 * pr_]; gsA.ay = Xv[mt_][2 * pr_ + 1]; gelu_nano<0>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]); } \
+            else if (st_ == 1) gelu_nano<1>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 2) gelu_nano<2>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 3) gelu_nano<3>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 4) gelu_nano<4>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 5) gelu_nano<5>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 6) gelu_nano<6>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 7) gelu_nano<7>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 8) gelu_nano<8>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 9) gelu_nano<9>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 10) gelu_nano<10>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 11) gelu_nano<11>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 12) gelu_nano<12>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 13) gelu_nano<13>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 14) gelu_nano<14>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 15) gelu_nano<15>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 16) gelu_nano<16>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 17) gelu_nano<17>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 18) gelu_nano<18>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 19) gelu_nano<19>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 20) gelu_nano<20>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 21) gelu_nano<21>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 22) gelu_nano<22>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 23) gelu_nano<23>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 24) gelu_nano<24>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 25) gelu_nano<25>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 26) gelu_nano<26>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 27) gelu_nano<27>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 28) gelu_nano<28>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 29) gelu_nano<29>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
         }
-#define ACX_TOUCH2(h_, l_) { asm volatile("" :: "v"(h_)); asm volatile("" :: "v"(l_)); }
+#define ACX_TOUCH2(h_, l_) asm volatile("" :: "v"(h_), "v"(l_));
 #define ACX_BIAS_INIT(j_)                                                                                       \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
             const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j_) + 8 * q + 4 * hh);                 \
@@ -220,18 +285,19 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             gl[pt_][1] = __builtin_bit_cast(f32x4, uint4{ul[pt_][4], ul[pt_][5], ul[pt_][6], ul[pt_][7]}); }
     // end of a segment: the pieces requested during it may stay in flight, everything older must have landed, and
     // every wave must be done reading the segment before its ring slot is requested again
-#define ACX_SEG_END(issued_)                                                                                    \
+#define ACX_SEG_END(issued_, stamp_)                                                                            \
         ACX_FENCE                                                                                               \
+        ACX_WSTAMP(stamp_)                                                                                      \
         if (issued_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::kPieces) : "memory");                       \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
         __builtin_amdgcn_s_barrier();                                                                           \
-        ACX_FENCE
+        ACX_FENCE                                                                                               \
+        ACX_WSTAMP(3)
 
     f32x16 Xn[PT], Xv[PT];        // Xn: pre-activation being accumulated by phase 1; Xv: the previous chunk's, input of the GELU
     f32x4 gh[PT][2], gl[PT][2];   // G(k - 1): B operand of phase 2, two k-steps, hi / lo halves
     unsigned uh[PT][8], ul[PT][8];
-    constexpr int kDmaStride = Cfg::kUnits / Cfg::kPieces;       // one piece every kDmaStride units
-    GeluState2 gsA, gsB;
+    GeluState2 gsA;
 
     // one phase-1 segment: X = b1 + W1c . LN(y)^T for chunk k_, image in ring slot grp_, requesting segment seg_ + 2
     auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
@@ -240,26 +306,30 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         const bool dma = seg_ + 2 < Cfg::kSegs;
         const int g2 = (grp_ + 2) % 3;
         ACX_BIAS_INIT(k_)
-        f32x4 a0h = ACX_W1_RD(base, 0, 0), a0l = ACX_W1_RD(base, 0, 1), a1h, a1l;
+        // fragments are read TWO units ahead of their MFMAs (three register sets rotating): with one unit of look-ahead
+        // (96 matrix cycles) the LDS latency under load was exposed in front of every unit
+        static_assert(Cfg::kSteps % 3 == 0, "the unit loop is unrolled by three");
+        f32x4 f0h = ACX_W1_RD(base, 0, 0), f0l = ACX_W1_RD(base, 0, 1), f1h = ACX_W1_RD(base, 1, 0), f1l = ACX_W1_RD(base, 1, 1),
+              f2h = ACX_W1_RD(base, 2, 0), f2l = ACX_W1_RD(base, 2, 1);
+        // unit s_: MFMAs on the current set; in the gap behind its last MFMA the (counted) wait for the NEXT unit's set, then
+        // the reads of unit s_ + 3 into the set just freed
+#define ACX_P1_UNIT(s_, ch_, cl_, th_, tl_)                                                                     \
+            ACX_FENCE                                                                                           \
+            ACX_P1_MFMA(s_, ch_, cl_)                                                                           \
+            if ((s_) + 1 < Cfg::kSteps) ACX_TOUCH2(th_, tl_)                                                    \
+            if ((s_) + 3 < Cfg::kSteps) { ch_ = ACX_W1_RD(base, (s_) + 3, 0); cl_ = ACX_W1_RD(base, (s_) + 3, 1); } \
+            ACX_FENCE
 #pragma unroll
-        for (int s = 0; s < Cfg::kSteps; s += 2) {
-            a1h = ACX_W1_RD(base, s + 1, 0); a1l = ACX_W1_RD(base, s + 1, 1);
-            ACX_FENCE
-            ACX_P1_MFMA(s, a0h, a0l)
-            if (s % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, s / kDmaStride, g2) }
-            ACX_FENCE
-            ACX_TOUCH2(a1h, a1l)
-            if (s + 2 < Cfg::kSteps) { a0h = ACX_W1_RD(base, s + 2, 0); a0l = ACX_W1_RD(base, s + 2, 1); }
-            ACX_FENCE
-            ACX_P1_MFMA(s + 1, a1h, a1l)
-            if ((s + 1) % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (s + 1) / kDmaStride, g2) }
-            ACX_FENCE
-            if (s + 2 < Cfg::kSteps) ACX_TOUCH2(a0h, a0l)
+        for (int s = 0; s < Cfg::kSteps; s += 3) {
+            ACX_P1_UNIT(s, f0h, f0l, f1h, f1l)
+            ACX_P1_UNIT(s + 1, f1h, f1l, f2h, f2l)
+            ACX_P1_UNIT(s + 2, f2h, f2l, f0h, f0l)
         }
+#undef ACX_P1_UNIT
         if constexpr (HV) { ACX_PACK_G() }
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) Xv[pt] = Xn[pt];
-        ACX_SEG_END(dma)
+        ACX_SEG_END(dma, 1)
     };
     // one phase-2 segment: out^T += W2c . G for the chunk whose G sits in gh / gl, image in ring slot grp_; with_gelu:
     // the first half of the GELU + split of Xv (the NEXT chunk) rides on this segment's MFMAs
@@ -268,29 +338,31 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         const char* base = smem + grp_ * Cfg::kSegBytes;
         const bool dma = seg_ + 2 < Cfg::kSegs;
         const int g2 = (grp_ + 2) % 3;
-        f32x4 a0h = ACX_W2_RD(base, 0, 0), a0l = ACX_W2_RD(base, 0, 1), a1h, a1l;
+        static_assert(Cfg::kUnits % 3 == 0, "the unit loop is unrolled by three");
+        f32x4 f0h = ACX_W2_RD(base, 0, 0), f0l = ACX_W2_RD(base, 0, 1), f1h = ACX_W2_RD(base, 1, 0), f1l = ACX_W2_RD(base, 1, 1),
+              f2h = ACX_W2_RD(base, 2, 0), f2l = ACX_W2_RD(base, 2, 1);
+#define ACX_P2_UNIT(i_, ch_, cl_, th_, tl_)                                                                     \
+            ACX_FENCE                                                                                           \
+            ACX_P2_MFMA(i_, ch_, cl_)                                                                           \
+            if ((i_) + 1 < Cfg::kUnits) ACX_TOUCH2(th_, tl_)                                                    \
+            if ((i_) + 3 < Cfg::kUnits) { ch_ = ACX_W2_RD(base, (i_) + 3, 0); cl_ = ACX_W2_RD(base, (i_) + 3, 1); } \
+            ACX_FENCE
 #pragma unroll
-        for (int i = 0; i < Cfg::kUnits; i += 2) {
-            a1h = ACX_W2_RD(base, i + 1, 0); a1l = ACX_W2_RD(base, i + 1, 1);
-            ACX_FENCE
-            ACX_P2_MFMA(i, a0h, a0l)
-            if (i % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, i / kDmaStride, g2) }
-            ACX_FENCE
-            ACX_TOUCH2(a1h, a1l)
-            if (i + 2 < Cfg::kUnits) { a0h = ACX_W2_RD(base, i + 2, 0); a0l = ACX_W2_RD(base, i + 2, 1); }
-            ACX_FENCE
-            ACX_P2_MFMA(i + 1, a1h, a1l)
-            if ((i + 1) % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (i + 1) / kDmaStride, g2) }
-            ACX_FENCE
-            if (i + 2 < Cfg::kUnits) ACX_TOUCH2(a0h, a0l)
+        for (int i = 0; i < Cfg::kUnits; i += 3) {
+            ACX_P2_UNIT(i, f0h, f0l, f1h, f1l)
+            ACX_P2_UNIT(i + 1, f1h, f1l, f2h, f2l)
+            ACX_P2_UNIT(i + 2, f2h, f2l, f0h, f0l)
         }
-        ACX_SEG_END(dma)
+#undef ACX_P2_UNIT
+        ACX_SEG_END(dma, 2)
     };
 
-    __syncthreads();      // segments 0 and 1 landed (hipcc drains the LDS-DMA before the barrier); b1s visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // segments 0 and 1 landed ...
+    __syncthreads();                                      // ... for every wave; b1s visible
+    ACX_WSTAMP(0)                                         // tile prologue: y rows, LayerNorm, first two segments' flight
     // segment 0: phase 1 of chunk 0; the first half of its GELU has nothing to ride on
     phase1(std::false_type{}, 0, 0, 0);
-    ACX_MICRO_RANGE(0, 0, Cfg::kHalf)
+    ACX_NANO_RANGE(0, 0, Cfg::kNano)
     // segments 2k-1 (phase 1 of chunk k + second half of GELU(k-1)) and 2k (phase 2 of chunk k-1 + first half of GELU(k));
     // ring slot = segment % 3
     int grp = 1;
@@ -315,7 +387,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     }
     phase2(std::true_type{}, 2 * n - 2, grp);
     grp = grp == 2 ? 0 : grp + 1;
-    ACX_MICRO_RANGE(1, 0, Cfg::kHalf)       // second half of the last chunk's GELU: no phase-1 segment left to ride on
+    ACX_NANO_RANGE(1, 0, Cfg::kNano)       // second half of the last chunk's GELU: no phase-1 segment left to ride on
     ACX_PACK_G()
     phase2(std::false_type{}, 2 * n - 1, grp);
 #undef ACX_WDMA
@@ -327,7 +399,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #undef ACX_P2_MFMA
 #undef ACX_TOUCH2
 #undef ACX_BIAS_INIT
-#undef ACX_MICRO_RANGE
+#undef ACX_NANO_RANGE
 #undef ACX_AFTER_MFMA
 #undef ACX_PACK_G
 #undef ACX_SEG_END
@@ -403,6 +475,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         }
     }
     }
+    ACX_WSTAMP(4)
+    ACX_WSTAMP_FLUSH
 }
 
 template <int C, int PT, bool LNOUT>

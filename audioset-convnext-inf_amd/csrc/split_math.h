@@ -98,6 +98,33 @@ __device__ __forceinline__ void gelu_micro(GeluState& s, const GeluConsts k, uns
 }
 
 
+// One 1-KB LDS-DMA piece (global_load_lds_dwordx4: lane l's 16 bytes from gsrc land at lds_dst + 16 l) issued from inline
+// asm, so that hipcc does NOT know an LDS write is in flight: next to the builtin form it orders the next LDS read of the
+// wave behind the DMA with s_waitcnt vmcnt(0) -- which also waits for every store and load the wave has in flight (a full
+// HBM round trip at each tile boundary of a persistent kernel).  The caller owns the ordering: a counted s_waitcnt vmcnt(N)
+// of its own (+ a barrier for other waves) between the piece and the reads of its bytes.  M0 carries the LDS base and is
+// restored (cdna_hip_programming.md 5.7).  lds_dst must be wave-uniform.
+__device__ __forceinline__ void acx_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// The same without saving M0 (three instructions instead of five): only for kernels in which nothing else uses M0 -- no
+// LDS-DMA builtin, no s_movrel, no GWS; the build checks the kernel's ISA for M0 uses outside these statements
+// (tools/check_exclusive.py).
+__device__ __forceinline__ void acx_glds16_own_m0(const void* gsrc, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// on ? a : b without a select the compiler could turn into a branch (a branch inside a hand-placed loop body splits it into
+// basic blocks and lets code sink out of its MFMA gaps)
+__device__ __forceinline__ unsigned acx_pick(bool on, unsigned a, unsigned b) {
+    const unsigned m = 0u - (unsigned)on;
+    return b ^ ((a ^ b) & m);
+}
+__device__ __forceinline__ unsigned acx_lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(p);
+}
+
 // ---- GELU + split, second form (round 3): 15 vector instructions per element instead of 17-19 -------------------------
 //   gelu(v) kH = 0.5 kH v + |v| kH (0.5 - 0.5 q(|v|)),   q = erfc(|v| / sqrt 2) = poly(t) t exp(-v^2 / 2)   (A&S 7.1.26)
 // With a = v / sinv (the accumulator's unit) and hb = 0.5 sinv kH:   g = fma(|a|, r, a hb),   r = fma(P, e, hb),
@@ -116,6 +143,12 @@ __device__ __forceinline__ GeluK2 gelu_k2(float sinv, float kh) {
     k.k1 = -k.hb * 0.254829592f; k.k2 = -k.hb * -0.284496736f; k.k3 = -k.hb * 1.421413741f;
     k.k4 = -k.hb * -1.453152027f; k.k5 = -k.hb * 1.061405429f;
     return k;
+}
+// Two waves per SIMD (mlp_fused_split.hip): a VALU instruction with a scalar-register operand issues at 4.2 cycles, the
+// same instruction on vector registers only at 2.2 (profiles/r03_c_valu_opcode_costs.txt) -- pin the eight constants in
+// VGPRs there.  At one wave per SIMD both forms cost the same; the wide kernels keep them scalar.
+__device__ __forceinline__ void gelu_k2_to_vgprs(GeluK2& k) {
+    asm volatile("" : "+v"(k.ps), "+v"(k.cq), "+v"(k.hb), "+v"(k.k1), "+v"(k.k2), "+v"(k.k3), "+v"(k.k4), "+v"(k.k5));
 }
 struct GeluState2 { float ax, ay, tx, ty, ex, ey, px, py; };
 __device__ __forceinline__ float acx_sub_hi_half(float g, unsigned h, const bool upper) {      // g - float(half of h)
@@ -156,5 +189,45 @@ __device__ __forceinline__ void gelu_micro2(GeluState2& s, const GeluK2 k, unsig
         lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
     }
 }
+
+// The same GELU + split as THIRTY single-instruction steps per register pair ("nano-steps"), for kernels that place
+// every filler of an MFMA gap by count: at one wave per SIMD up to five single-issue instructions per v_mfma_f32_32x32x16
+// gap are free and each further one costs ~5 cycles (profiles/r03_a_coissue_table.txt), so what matters is that NO gap
+// carries more than its budget -- the eight micro-steps above (2-6 instructions each, next to a gap's fragment reads, wait and
+// LDS-DMA piece) left gaps of 9-13 fillers beside bursts of bare MFMAs.  Same arithmetic, same order, same rounding.
+template <int I>
+__device__ __forceinline__ void gelu_nano(GeluState2& s, const GeluK2 k, unsigned& hi, unsigned& lo) {
+    if constexpr (I == 0) s.tx = __builtin_fmaf(__builtin_fabsf(s.ax), k.ps, 1.0f);
+    else if constexpr (I == 1) s.ty = __builtin_fmaf(__builtin_fabsf(s.ay), k.ps, 1.0f);
+    else if constexpr (I == 2) s.tx = __builtin_amdgcn_rcpf(s.tx);
+    else if constexpr (I == 3) s.ty = __builtin_amdgcn_rcpf(s.ty);
+    else if constexpr (I == 4) s.ex = s.ax * k.cq;
+    else if constexpr (I == 5) s.ey = s.ay * k.cq;
+    else if constexpr (I == 6) s.ex = -(s.ex * s.ex);
+    else if constexpr (I == 7) s.ex = __builtin_amdgcn_exp2f(s.ex);
+    else if constexpr (I == 8) s.ey = -(s.ey * s.ey);
+    else if constexpr (I == 9) s.ey = __builtin_amdgcn_exp2f(s.ey);
+    else if constexpr (I == 10) s.px = __builtin_fmaf(s.tx, k.k5, k.k4);
+    else if constexpr (I == 11) s.py = __builtin_fmaf(s.ty, k.k5, k.k4);
+    else if constexpr (I == 12) s.px = __builtin_fmaf(s.px, s.tx, k.k3);
+    else if constexpr (I == 13) s.py = __builtin_fmaf(s.py, s.ty, k.k3);
+    else if constexpr (I == 14) s.px = __builtin_fmaf(s.px, s.tx, k.k2);
+    else if constexpr (I == 15) s.py = __builtin_fmaf(s.py, s.ty, k.k2);
+    else if constexpr (I == 16) s.px = __builtin_fmaf(s.px, s.tx, k.k1);
+    else if constexpr (I == 17) s.py = __builtin_fmaf(s.py, s.ty, k.k1);
+    else if constexpr (I == 18) s.px *= s.tx;
+    else if constexpr (I == 19) s.py *= s.ty;
+    else if constexpr (I == 20) s.px = __builtin_fmaf(s.px, s.ex, k.hb);
+    else if constexpr (I == 21) s.py = __builtin_fmaf(s.py, s.ey, k.hb);
+    else if constexpr (I == 22) s.tx = s.ax * k.hb;
+    else if constexpr (I == 23) s.ty = s.ay * k.hb;
+    else if constexpr (I == 24) s.ex = __builtin_fmaf(__builtin_fabsf(s.ax), s.px, s.tx);
+    else if constexpr (I == 25) s.ey = __builtin_fmaf(__builtin_fabsf(s.ay), s.py, s.ty);
+    else if constexpr (I == 26) { f32x2 g; g.x = s.ex; g.y = s.ey; hi = __builtin_bit_cast(unsigned, __builtin_convertvector(g, h2)); }
+    else if constexpr (I == 27) s.px = acx_sub_hi_half(s.ex, hi, false);
+    else if constexpr (I == 28) s.py = acx_sub_hi_half(s.ey, hi, true);
+    else { f32x2 r; r.x = s.px; r.y = s.py; lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2)); }
+}
+constexpr int kGeluNano = 30;       // nano-steps per register pair
 
 }  // namespace acx

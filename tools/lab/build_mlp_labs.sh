@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../.."
 S=$PWD/audioset-convnext-inf_amd/csrc; O=build/labs; mkdir -p $O
 build() {   # name, source, C, launcher, extra flags
-  hipcc -O3 -std=c++17 -fno-slp-vectorize --offload-arch=gfx950 -w -DWIDE_C=$3 -DWIDE_FN=$4 -DWIDE_SRC="\"$2\"" $5 tools/wide_lab.hip -o $O/$1 &
+  hipcc -O3 -std=c++17 -fno-slp-vectorize -mllvm -pragma-unroll-threshold=4000000 --offload-arch=gfx950 -w -DWIDE_C=$3 -DWIDE_FN=$4 -DWIDE_SRC="\"$2\"" $5 tools/wide_lab.hip -o $O/$1 &
 }
 build mlp_c96_new  $S/mlp_fused_split.hip 96  launch_mlp_fused_split
 build mlp_c192_new $S/mlp_fused_wide.hip  192 launch_mlp_fused_wide

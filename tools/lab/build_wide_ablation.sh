@@ -1,0 +1,26 @@
+#!/bin/bash
+# Ablation variants of the wide fused MLP kernel (mlp_fused_wide.hip), built HERE into build/labs/ablw<C>_*; run on the GPU box:
+#   for b in build/labs/ablw384_*; do echo -n "$(basename $b): "; $b; done
+# Outputs of the variants are wrong by construction; only their run time matters.
+set -e
+cd "$(dirname "$0")/../.."
+S=$PWD/audioset-convnext-inf_amd/csrc; O=build/labs; mkdir -p $O/src
+C=${1:-384}
+variant() {   # name, sed expressions...
+  local name=$1; shift
+  cp $S/mlp_fused_wide.hip $O/src/ablw${C}_$name.hip
+  for e in "$@"; do sed -i -E "$e" $O/src/ablw${C}_$name.hip; done
+  sed -i 's#"acx_internal.h"#"'$S'/acx_internal.h"#; s#"split_math.h"#"'$S'/split_math.h"#' $O/src/ablw${C}_$name.hip
+  hipcc -O3 -std=c++17 -fno-slp-vectorize -mllvm -pragma-unroll-threshold=4000000 --offload-arch=gfx950 -w $EXTRA -DWIDE_C=$C -DWIDE_FN=launch_mlp_fused_wide -DWIDE_SRC="\"$PWD/$O/src/ablw${C}_$name.hip\"" tools/wide_lab.hip -o $O/ablw${C}_$name &
+}
+variant full
+EXTRA=-DACX_FW_STAMPS variant stamps
+variant nogelu 's/^(\s+)ACX_FENCE if constexpr \(HV_\) \{ ACX_MICRO_RANGE.*$/\1ACX_FENCE/'
+variant nodma 's/^        acx_glds16_own_m0\(wstream/        if (0) acx_glds16_own_m0(wstream/'
+variant nobarrier 's/^        __builtin_amdgcn_s_barrier\(\);  /  /'
+variant nodsread 's/^#define ACX_W1_RD\(base_, s_, pl_\).*/#define ACX_W1_RD(base_, s_, pl_) (acth[0][(s_) % 4])/; s/^#define ACX_W2_RD\(base_, i_, pl_\).*/#define ACX_W2_RD(base_, i_, pl_) (actl[0][(i_) % 4])/'
+variant nomfma 's/^(\s+)(Xn\[pt_\]|acc\[pt_\]\[\(i_\) >> 1\]) = __builtin_amdgcn_mfma_f32_32x32x16_f16\((ACX_H8\([a-z_]+\)), (ACX_H8\([^)]*\)\)?), .*$/\1asm volatile("" :: "v"(\3), "v"(\4)); \\/'
+EXTRA=-DACX_FW_STAMPS variant stamps_nomfma 's/^(\s+)(Xn\[pt_\]|acc\[pt_\]\[\(i_\) >> 1\]) = __builtin_amdgcn_mfma_f32_32x32x16_f16\((ACX_H8\([a-z_]+\)), (ACX_H8\([^)]*\)\)?), .*$/\1asm volatile("" :: "v"(\3), "v"(\4)); \\/'
+wait
+for v in nogelu nodma nobarrier nodsread nomfma; do echo "$v: $(diff $O/src/ablw${C}_full.hip $O/src/ablw${C}_$v.hip | grep -c '^[<>]') changed lines"; done
+ls $O | grep ablw$C

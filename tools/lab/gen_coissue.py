@@ -57,6 +57,28 @@ def cvt_mix(n):                  # the split's instructions: v_cvt_pk_f16_f32 + 
         return out
     return f
 
+def op(fmt, n):                  # n copies per gap of one instruction form; {r} = rotating register f0..f7, {q} = the next one
+    def f(g):
+        out = []
+        for i in range(n):
+            r = (g * n + i) % 8
+            out.append(fmt.replace("{r}", "%[f" + str(r) + "]").replace("{q}", "%[f" + str((r + 1) % 8) + "]"))
+        return out
+    return f
+
+OPS = {   # VALU-only issue cost per opcode form, one and two waves per SIMD
+    "fma_vvv": "v_fma_f32 {r}, {r}, %%[c1], %%[c2]",
+    "fma_sgpr": "v_fma_f32 {r}, {r}, %%[s1], %%[c2]",
+    "fma_abs": "v_fma_f32 {r}, |{r}|, %%[c1], %%[c2]",
+    "fmaak": "v_fmaak_f32 {r}, {r}, %%[c1], 0x3f7fbe77",
+    "mul_e32": "v_mul_f32 {r}, %%[c1], {r}",
+    "exp": "v_exp_f32 {r}, {r}",
+    "rcp": "v_rcp_f32 {r}, {r}",
+    "cvt_pk": "v_cvt_pk_f16_f32 {r}, {r}, {q}",
+    "fma_mix": "v_fma_mix_f32 {r}, {r}, 1.0, -{q} op_sel_hi:[0,0,1]",
+    "mov": "v_mov_b32 {r}, {q}",
+}
+
 # name -> (mfma?, filler fn or None, waves per workgroup, role)   role: 'all' every wave runs the stream;
 # 'split' waves 0-3 MFMA only / waves 4-7 fillers only (SIMD partners: waves w and w+4 share a SIMD)
 VARIANTS = []
@@ -78,6 +100,42 @@ for (r, f) in ((1, 0), (2, 0), (1, 4), (2, 3)):
     VARIANTS.append(("mfma_ds%d_fma%d_w4" % (r, f), True, dsread(r, f), 4, "all", r + f, "ds"))
 for n in (3, 5):
     VARIANTS.append(("mfma_cvtmix%d_w4" % n, True, cvt_mix(n), 4, "all", n, "mix"))
+def unit_pattern(g):              # the wide kernel's unit: gaps 0,1: 3 plain; gap 2: counted wait + two fragment reads + 1 plain
+    r = (3 * g) % 8
+    if g % 3 == 2:
+        return ["s_waitcnt lgkmcnt(2)", "ds_read_b128 %%[d%d], %%[la] offset:%d" % ((2 * (g // 3)) % 4, ((2 * (g // 3)) % 16) * 1024),
+                "ds_read_b128 %%[d%d], %%[la] offset:%d" % ((2 * (g // 3) + 1) % 4, ((2 * (g // 3) + 1) % 16) * 1024),
+                "v_fma_f32 %%[f%d], %%[f%d], %%[c1], %%[c2]" % (r, r)]
+    return ["v_fma_f32 %%[f%d], %%[f%d], %%[c1], %%[c2]" % ((r + i) % 8, (r + i) % 8) for i in range(3)]
+
+def unit_pattern_trans(g):        # the same with the GELU's transcendentals: one v_exp / v_rcp in every plain gap
+    out = unit_pattern(g)
+    if g % 3 != 2:
+        out[1] = "v_exp_f32 %%[f%d], %%[f%d]" % ((3 * g + 1) % 8, (3 * g + 1) % 8)
+    return out
+
+def unit_pattern_m0(g):           # + an LDS-DMA-like scalar clump (s_mov m0 / s_nop) in the first gap of every other unit
+    out = unit_pattern(g)
+    if g % 6 == 0:
+        out = ["s_mov_b32 m0, %%[sa]", "s_nop 0", "v_mov_b32 %%[f7], %%[f6]"] + out[:1]
+    return out
+
+VARIANTS.append(("chain1_fma4_w4", True, fma(4), 4, "chain1", 4, "fma"))
+VARIANTS.append(("chain6_fma4_w4", True, fma(4), 4, "chain6", 4, "fma"))
+VARIANTS.append(("unit_w4", True, unit_pattern, 4, "all", 4, "unit"))
+VARIANTS.append(("unit_chain1_w4", True, unit_pattern, 4, "chain1", 4, "unit"))
+VARIANTS.append(("unit_trans_chain1_w4", True, unit_pattern_trans, 4, "chain1", 4, "unit"))
+VARIANTS.append(("unit_m0_chain1_w4", True, unit_pattern_m0, 4, "chain1", 4, "unit"))
+for name_, fmt_ in OPS.items():
+    for w_ in (4, 8):
+        VARIANTS.append(("valu_only_%s_w%d" % (name_, w_), False, op(fmt_, 6), w_, "all", 6, "op"))
+# two-segment streams (8 waves): seg 1 = 16 x (MFMA + a fillers), barrier, seg 2 = 16 x b fillers, barrier; the GELU's mix
+# (5 plain : 1 transcendental).  'stagger': waves 4-7 run seg 2 first, so a SIMD's two waves are always in different segments;
+# 'lockstep': same order in all waves.  uniform reference: 16 x (MFMA + a + b fillers), one segment.
+for (a_, b_) in ((4, 4), (3, 5), (5, 3), (2, 6)):
+    VARIANTS.append(("seg_stagger_%d_%d_w8" % (a_, b_), True, (mul_exp(a_ - 1, 1) if a_ > 1 else fma(a_), mul_exp(b_ - 1, 1)), 8, "stagger", a_ + b_, "seg"))
+    VARIANTS.append(("seg_lockstep_%d_%d_w8" % (a_, b_), True, (mul_exp(a_ - 1, 1) if a_ > 1 else fma(a_), mul_exp(b_ - 1, 1)), 8, "lockstep", a_ + b_, "seg"))
+VARIANTS.append(("uniform_fma6_exp2_w8", True, mul_exp(6, 2), 8, "all", 8, "fma+exp"))
 VARIANTS.append(("split_mfma_vs_fma6_w8", True, fma(6), 8, "split", 6, "fma"))
 VARIANTS.append(("split_mfma_vs_fma12_w8", True, fma(12), 8, "split", 12, "fma"))
 
@@ -86,7 +144,7 @@ MF = "v_mfma_f32_32x32x16_f16 %%[acc%d], %%[a], %%[b], %%[acc%d]"
 OPERANDS = (': [acc0] "+v"(acc0), [acc1] "+v"(acc1), [f0] "+v"(f[0]), [f1] "+v"(f[1]), [f2] "+v"(f[2]), [f3] "+v"(f[3]), '
             '[f4] "+v"(f[4]), [f5] "+v"(f[5]), [f6] "+v"(f[6]), [f7] "+v"(f[7]), [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), '
             '[p3] "+v"(p[3]), [d0] "=&v"(d[0]), [d1] "=&v"(d[1]), [d2] "=&v"(d[2]), [d3] "=&v"(d[3])\n'
-            '            : [a] "v"(a), [b] "v"(b), [c1] "v"(c1), [c2] "v"(c2), [pc] "v"(pc), [la] "v"(la) : "memory"')
+            '            : [a] "v"(a), [b] "v"(b), [c1] "v"(c1), [c2] "v"(c2), [pc] "v"(pc), [la] "v"(la), [s1] "s"(s1), [sa] "s"(sa) : "memory"')
 
 
 def asm_block(lines):
@@ -95,11 +153,29 @@ def asm_block(lines):
 
 
 def kernel(name, mfma, filler, waves, role):
+    if role in ("stagger", "lockstep"):
+        f1, f2 = filler
+        seg1, seg2 = [], []
+        for g in range(NM):
+            seg1.append(MF % (g & 1, g & 1)); seg1 += f1(g)
+            seg2 += f2(g)
+        out = []
+        out.append("extern \"C\" __global__ __launch_bounds__(%d) void %s(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ cyc, int iters) {\n" % (waves * 64, name))
+        out.append("    PROLOGUE\n")
+        out.append("    const bool late = %s;\n" % ("__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4" if role == "stagger" else "false"))
+        out.append("    const unsigned long long t0 = stamp();\n")
+        out.append("    if (late) {\n" + asm_block(seg2) + "      __builtin_amdgcn_s_barrier();\n    }\n")
+        out.append("    for (int it = 0; it < iters; ++it) {\n" + asm_block(seg1) + "      __builtin_amdgcn_s_barrier();\n" + asm_block(seg2) + "      __builtin_amdgcn_s_barrier();\n    }\n")
+        out.append("    if (late) {\n" + asm_block(seg1) + "    }\n")
+        out.append("    const unsigned long long t1 = stamp();\n")
+        out.append("    EPILOGUE\n}\n\n")
+        return "".join(out)
     both, only_m, only_v = [], [], []
     for g in range(NM):
         fl = filler(g) if filler else []
+        a_ = 0 if role == "chain1" else ((g // 6) & 1 if role == "chain6" else g & 1)
         if mfma:
-            both.append(MF % (g & 1, g & 1)); only_m.append(MF % (g & 1, g & 1))
+            both.append(MF % (a_, a_)); only_m.append(MF % (a_, a_))
         both += fl; only_v += fl
     out = []
     out.append("extern \"C\" __global__ __launch_bounds__(%d) void %s(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ cyc, int iters) {\n" % (waves * 64, name))
@@ -151,7 +227,9 @@ __device__ __forceinline__ unsigned long long stamp() {
     f32x2 pc; pc.x = 0.999f; pc.y = 0.998f;                                                                   \
     f32x4 d[4];                                                                                               \
     const float c1 = 0.9999f, c2 = 1e-4f;                                                                     \
-    const unsigned la = (unsigned)(tid & 63) * 16;
+    const unsigned la = (unsigned)(tid & 63) * 16;                                                            \
+    const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, c1)));  \
+    const unsigned sa = __builtin_amdgcn_readfirstlane(la) & 0xfc00;
 
 #define EPILOGUE                                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \

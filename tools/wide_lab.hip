@@ -56,5 +56,37 @@ int main(int argc, char** argv) {
     }
     const double tf = 4.0 * M * C * 4 * C / (best * 1e-3) / 1e12;
     printf("M=%lld: %.1f us per block, %.1f TF fp32-equivalent = %.3f of 833\n", M, best * 1e3, tf, tf / 833.3);
+#ifdef ACX_FW_STAMPS
+    {   // wide kernel: per-wave section sums of the LAST launch (s_memtime ticks), averaged over the first 2048 workgroups
+        static unsigned long long st[2048 * 4 * 8];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(acx::acx_fw_stamps), sizeof(st));
+        const char* names[8] = {"prologue", "phase-1 segments", "phase-2 segments", "segment-end wait+barrier", "epilogue", "-", "-", "-"};
+        const long long wgs = (M + 127) / 128 < 2048 ? (M + 127) / 128 : 2048;
+        for (int w : {0, 3}) {
+            double sum[8] = {0};
+            for (int b = 0; b < wgs; ++b) for (int k = 0; k < 8; ++k) sum[k] += (double)st[(b * 4 + w) * 8 + k];
+            double tot = 0; for (int k = 0; k < 5; ++k) tot += sum[k];
+            printf("   wave %d: ticks per tile:", w);
+            for (int k = 0; k < 5; ++k) printf(" %s %.0f |", names[k], sum[k] / wgs);
+            printf(" total %.0f\n", tot / wgs);
+        }
+    }
+#endif
+#ifdef ACX_FS_STAMPS
+    {   // per-wave section sums of the LAST launch (s_memtime ticks): average over workgroups, waves 0 and 4
+        static unsigned long long st[256 * 8 * 8];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(acx::acx_fs_stamps), sizeof(st));
+        const char* names[8] = {"prologue", "phase1+gelu", "phase2+gelu", "pack+copy", "wait+barrier", "short iters phase2", "epilogue", "-"};
+        const long long tiles_total = (M + 255) / 256;
+        for (int w : {0, 4}) {
+            double sum[8] = {0};
+            for (int b = 0; b < 256; ++b) for (int k = 0; k < 8; ++k) sum[k] += (double)st[(b * 8 + w) * 8 + k];
+            double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
+            printf("   wave %d: ticks per tile:", w);
+            for (int k = 0; k < 7; ++k) printf(" %s %.0f |", names[k], sum[k] / tiles_total);
+            printf(" total %.0f\n", tot / tiles_total);
+        }
+    }
+#endif
     return 0;
 }
