@@ -588,6 +588,29 @@ static int check_stage(int stage, int block) {
 
 using namespace acx;
 
+// side stream + fork/join events of the two-stream batch split, one set per caller stream.  The set of the null stream is
+// created in acx_create; any other stream gets its set at its first split forward -- which must not be a stream capture
+// (hipStreamCreate inside a capture region): warm up once on the stream before capturing, as the host wrapper does.
+// A partial failure destroys what it created; the map is bounded (sets of the least recently added streams are dropped).
+static int make_aux(acx_ctx::Aux* a) {
+    *a = acx_ctx::Aux{};
+    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&a->fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&a->join, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (a->join) (void)hipEventDestroy(a->join);
+        if (a->fork) (void)hipEventDestroy(a->fork);
+        if (a->stream) (void)hipStreamDestroy(a->stream);
+        *a = acx_ctx::Aux{};
+        ACX_FAIL(ACX_ERR_HIP, "side stream / events of the two-stream split: %s", hipGetErrorString(e));
+    }
+    return ACX_OK;
+}
+static void destroy_aux(acx_ctx::Aux& a) {
+    if (a.fork) (void)hipEventDestroy(a.fork);
+    if (a.join) (void)hipEventDestroy(a.join);
+    if (a.stream) (void)hipStreamDestroy(a.stream);
+}
 extern "C" {
 
 const char* acx_last_error(void) { return g_err; }
@@ -612,6 +635,12 @@ int acx_create(int hip_device, acx_ctx** out) {
         const char* e2 = std::getenv("ACX_SPLIT_TWO_STREAMS");
         c->split_two_streams = e2 && e2[0] == '1';
     }
+    {   // the null stream's side stream + events exist from the start (nothing is created inside a capture)
+        acx_ctx::Aux a;
+        int rc = make_aux(&a);
+        if (rc != ACX_OK) { delete c; return rc; }
+        c->aux.emplace((hipStream_t) nullptr, a);
+    }
     *out = c;
     return ACX_OK;
 }
@@ -622,11 +651,7 @@ void acx_destroy(acx_ctx* c) {
     free_device(c);
     for (auto& r : c->prof.recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
-    for (auto& kv : c->aux) {
-        if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
-        if (kv.second.join) (void)hipEventDestroy(kv.second.join);
-        if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
-    }
+    for (auto& kv : c->aux) destroy_aux(kv.second);
     delete c;
 }
 
@@ -695,15 +720,21 @@ int acx_workspace_bytes(const acx_ctx* c, int B, int64_t L, int mode, size_t* ou
     return ACX_OK;
 }
 
-// side stream + fork/join events of the two-stream batch split, one set per caller stream (created on first use)
+static constexpr size_t kMaxAuxStreams = 16;
 static int get_aux(acx_ctx* c, hipStream_t st, acx_ctx::Aux* out) {
     std::lock_guard<std::mutex> lock(c->aux_mutex);
     auto it = c->aux.find(st);
     if (it == c->aux.end()) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            ACX_FAIL(ACX_ERR_STATE, "first two-stream forward on this stream happens inside a stream capture: run one forward on "
+                                    "the stream before capturing (the side stream and its events are created then)");
         acx_ctx::Aux a;
-        ACX_HIP(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
-        ACX_HIP(hipEventCreateWithFlags(&a.fork, hipEventDisableTiming));
-        ACX_HIP(hipEventCreateWithFlags(&a.join, hipEventDisableTiming));
+        ACX_TRY(make_aux(&a));
+        if (c->aux.size() >= kMaxAuxStreams) {          // drop a set that is not the null stream's
+            for (auto d = c->aux.begin(); d != c->aux.end(); ++d)
+                if (d->first != nullptr) { (void)hipStreamSynchronize(d->second.stream); destroy_aux(d->second); c->aux.erase(d); break; }
+        }
         it = c->aux.emplace(st, a).first;
     }
     *out = it->second;

@@ -134,9 +134,12 @@ class ConvNeXt(nn.Module):
         if self.precision not in _ffi.PRECISIONS:
             raise ValueError("ACX_PRECISION must be one of %s" % sorted(_ffi.PRECISIONS))
         self._ws = {}           # (device index, stream handle) -> workspace tensor: concurrent forwards on different
-        #                         streams never share scratch memory (the reference module is re-entrant in eval)
-        self._ws_retired = []   # outgrown workspaces stay alive: a captured hipGraph may still point into them
+        #                         streams never share scratch memory (the reference module is re-entrant in eval).
+        #                         Insertion-ordered, most recently used last; at most _WS_MAX_STREAMS entries are kept
+        self._ws_captured = set()   # data pointers of workspaces a stream capture has seen: a hipGraph may point into them
+        self._ws_retired = []   # replaced workspaces that a captured graph may still reference (only those) stay alive
         self._weights_epoch = 0  # bumped by load_state_dict / _apply / refresh(): forces a repack of the native weights
+        self._sig_cache = None  # (epoch, [parameter and buffer tensors]) -- see _signature
 
     def _init_weights(self, m):
         if isinstance(m, (nn.Conv2d, nn.Linear)):
@@ -145,8 +148,13 @@ class ConvNeXt(nn.Module):
 
     # ------------------------------------------------------------------------------ native side
     def _signature(self):
-        return (self.precision, self._weights_epoch) + tuple((t.data_ptr(), t._version)
-                                                             for t in self.state_dict(keep_vars=True).values())
+        """Changes whenever the weights may have: the epoch counter (load_state_dict / _apply / refresh) plus every tensor's
+        storage address and autograd version.  The tensor list is cached per epoch -- state_dict() builds 190 prefixed keys
+        and cost 0.6 ms per forward, ten times the rest of the host path at batch 1 (profiles/r03_f_latency_bs1.txt)."""
+        c = self._sig_cache
+        if c is None or c[0] != self._weights_epoch:
+            c = self._sig_cache = (self._weights_epoch, list(self.state_dict(keep_vars=True).values()))
+        return (self.precision, self._weights_epoch) + tuple((t.data_ptr(), t._version) for t in c[1])
 
     def refresh(self):
         """Call after editing weights in a way autograd's version counters cannot see (`param.data.mul_(...)`, writes
@@ -172,12 +180,13 @@ class ConvNeXt(nn.Module):
             self._ws.pop(key)
         if keep is None:
             self._ws_retired.clear()
+            self._ws_captured.clear()
         return out
 
     def __getstate__(self):
         # native handles (ctypes) and scratch tensors are per-process state, rebuilt on demand
         state = self.__dict__.copy()
-        state["_ctx"], state["_ws"], state["_ws_retired"] = {}, {}, []
+        state["_ctx"], state["_ws"], state["_ws_retired"], state["_ws_captured"], state["_sig_cache"] = {}, {}, [], set(), None
         return state
 
     def __deepcopy__(self, memo):
@@ -186,7 +195,16 @@ class ConvNeXt(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = {} if k in ("_ctx", "_ws") else ([] if k == "_ws_retired" else copy.deepcopy(v, memo))
+            if k in ("_ctx", "_ws"):
+                new.__dict__[k] = {}
+            elif k == "_ws_retired":
+                new.__dict__[k] = []
+            elif k == "_ws_captured":
+                new.__dict__[k] = set()
+            elif k == "_sig_cache":
+                new.__dict__[k] = None
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 
     def set_precision(self, precision):
@@ -213,16 +231,30 @@ class ConvNeXt(nn.Module):
         self._ctx[idx] = (ctx, sig)
         return ctx
 
+    _WS_MAX_STREAMS = 8      # workspaces kept per module (one per (device, stream) in use); the least recently used goes first
+
     def _workspace(self, device, nbytes):
+        """Scratch memory of one forward on (device, current stream).  Grows geometrically (a length-sorted sweep would
+        otherwise reallocate at every new maximum); a replaced or evicted workspace is freed unless a stream capture has
+        seen it -- a captured hipGraph replays with the pointers it recorded, so those stay alive with the module."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
         key = (idx, torch.cuda.current_stream(device).cuda_stream)
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)
         if ws is None or ws.numel() < nbytes:
             if ws is not None:
-                self._ws_retired.append(ws)
+                self._retire(ws)
+                nbytes = max(nbytes, ws.numel() + ws.numel() // 2)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._ws[key] = ws
+        self._ws[key] = ws                      # (re-)inserted last: most recently used
+        while len(self._ws) > self._WS_MAX_STREAMS:
+            self._retire(self._ws.pop(next(iter(self._ws))))
+        if torch.cuda.is_current_stream_capturing():
+            self._ws_captured.add(ws.data_ptr())
         return ws
+
+    def _retire(self, ws):
+        if ws.data_ptr() in self._ws_captured:
+            self._ws_retired.append(ws)
 
     def _run(self, x, mode):
         if self.training:

@@ -193,7 +193,7 @@ def self_launch(n, argv):
     import subprocess
     dry = "--dry-run" in argv
     if not dry:
-        have = torch.cuda.device_count()          # counts devices without initialising the GPU runtime state
+        have = torch.cuda.device_count()          # (the ranks are fresh child processes: nothing here is inherited by them)
         if have < n:
             print("bench.py: --gpus %d requested but only %d GPU(s) visible" % (n, have), file=sys.stderr)
             return 2
@@ -204,12 +204,40 @@ def self_launch(n, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # Poll ALL ranks: when one dies early (bad device, import error) the others would sit in the rendezvous until the
+    # process-group timeout -- stop them instead and report the first failure.  Rank 0's line is read by a thread so that
+    # a full pipe never blocks it.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     if any(rcs):
-        print("bench.py: rank exit codes %s" % rcs, file=sys.stderr)
+        print("bench.py: rank exit codes %s%s" % (rcs, "" if failed is None else " (rank %d failed first; the others were stopped)" % failed),
+              file=sys.stderr)
         return 1
     return 0
 
@@ -243,6 +271,8 @@ def main():
         if rank == 0:
             print("bench.py: --gpus %d disagrees with WORLD_SIZE %d set by the launcher" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    if args.dry_run and os.environ.get("ACX_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        sys.exit(7)          # test hook (tests/test_host_cpu.py): a rank that dies before the rendezvous
     dist = None
     dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local_rank)
     if world > 1:

@@ -81,6 +81,31 @@ def test_logmel_kernel(ctx, taps):
     assert float(d2[strong].max()) < 5e-3
 
 
+def test_logmel_kernel_vs_torch_stft(ctx, golden_dir):
+    """The frontend kernel against a path that shares no code with the oracle's restatement of torchlibrosa: torch.stft
+    (scipy's periodic hann, center / reflect, hop 320) -> power -> mel matrix -> dB, in float64, on the reference's demo
+    clip (convnext.py:179-200, 298-299).  Same dB criterion as test_logmel_kernel."""
+    import scipy.signal
+    from oracle import torchlibrosa_spec as tls
+    pcm = np.load(os.path.join(golden_dir, "g1_demo.npz"))["pcm16"]
+    wav = torch.from_numpy(pcm.astype(np.float32) / 32768.0)[None, :]
+    L = wav.shape[1]
+    T = _ffi.num_frames(L)
+    out = torch.empty(1, T, 224, device="cuda")
+    wav_d = wav.cuda()
+    _ffi.check(_ffi.lib().acx_logmel_bn0(ctx.handle, _ffi.ptr(wav_d), 1, L, _ffi.ptr(out), 0, sp()))
+    win = torch.from_numpy(scipy.signal.get_window("hann", 1024, fftbins=True))
+    st = torch.stft(wav.double(), 1024, 320, 1024, window=win, center=True, pad_mode="reflect", return_complex=True)
+    power = (st.abs() ** 2).transpose(1, 2)                                       # (1, T, 513)
+    assert power.shape[1] == T
+    mel = power @ torch.from_numpy(tls.melW()).double()
+    ref = 10.0 * torch.log10(mel.clamp_min(1e-10))
+    d = (out.cpu().double() - ref).abs()
+    strong = ref > (ref.max() - 90.0)
+    assert float(d[strong].max()) < 0.02, float(d[strong].max())
+    assert float(d.mean()) < 0.05
+
+
 def test_stem_kernel(ctx, taps):
     x = taps["bn0"][:, 0].contiguous().cuda()          # (B,T,224)
     B, T, _ = x.shape
@@ -269,6 +294,32 @@ def test_weight_reload_is_picked_up(synth_sd):
     ref.load_state_dict(synth_sd)
     c = ref.to("cuda").eval()(wav)["clipwise_logits"]
     assert torch.equal(b, c)
+
+
+def test_workspace_growth_and_pruning(synth_sd):
+    """Host-side scratch policy: one workspace per (device, stream), geometric growth, nothing retired unless a
+    stream capture has seen it, at most _WS_MAX_STREAMS live workspaces."""
+    m = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56], use_speed_perturb=False)
+    m.load_state_dict(synth_sd)
+    m = m.to("cuda").eval()
+    wav = synth.synth_waveforms(1, 64000, seed=2).cuda()
+    sizes = []
+    for L in (16000, 17000, 18000, 30000, 64000):            # a length-sorted sweep: each clip a little longer
+        m(wav[:, :L])
+        assert len(m._ws) == 1 and not m._ws_retired
+        sizes.append(next(iter(m._ws.values())).numel())
+    torch.cuda.synchronize()
+    grown = [b for a, b in zip(sizes, sizes[1:]) if b != a]
+    assert len(grown) <= 3 and all(b >= a + a // 2 for a, b in zip(sizes, sizes[1:]) if b != a), sizes
+    ref = m(wav[:, :16000])["clipwise_logits"].clone()
+    streams = [torch.cuda.Stream() for _ in range(m._WS_MAX_STREAMS + 3)]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            out = m(wav[:, :16000])["clipwise_logits"]
+        st.synchronize()
+        assert torch.equal(out, ref)
+    assert len(m._ws) == m._WS_MAX_STREAMS and not m._ws_retired
 
 
 def test_forward_is_graph_capturable(model):

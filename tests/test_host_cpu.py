@@ -159,3 +159,12 @@ def test_bench_self_launch_dry_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
                        text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"))
     assert r.returncode == 2 and "disagrees" in r.stderr
+    # a rank that dies before the rendezvous: the launcher stops the others at once instead of waiting out the
+    # process-group timeout
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch", "2", "--dry-run"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, ACX_BENCH_DRYRUN_FAIL_RANK="1"))
+    assert r.returncode == 1 and "rank 1 failed first" in r.stderr, r.stderr[-800:]
+    assert time.time() - t0 < 120

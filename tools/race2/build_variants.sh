@@ -1,5 +1,9 @@
 #!/bin/bash
-# Builds diagnostic variants of libacx (kernel sources WITH the lab switches: tools/lab_src/) into build/variants/ (run here; the .so files travel with gpurun).
+# ROUND-2 RECORD: builds the diagnostic variants of libacx that sessions 1-8 ran.  They were compiled from
+# kernel sources WITH lab switches (tools/lab_src/ at commit eaa811c, removed from the tree in round 3 because the copies had
+# drifted from csrc/): check that commit out to rebuild them.  The round-3 way: tools/lab/build_variant_lib.sh + an override
+# directory (e.g. a gemm_split.hip without the CU-exclusive claim), tools/race2/run_detect.py with ACX_LIB=...,
+# and tools/race2/standalone_repro.hip (no libacx at all).
 set -e
 cd "$(dirname "$0")/../.."
 CS=audioset-convnext-inf_amd/csrc

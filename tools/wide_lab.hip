@@ -1,6 +1,7 @@
 // Stand-alone timing lab for the wide fused MLP kernel (not part of libacx):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -w -DWIDE_SRC='"path/to/mlp_fused_wide.hip"' tools/wide_lab.hip -o /tmp/wide_lab
-// tools/run_wide_lab.sh builds sed-patched variants of the product source (no DMA, no GELU, ...) and runs them all.
+// tools/lab/build_mlp_labs.sh, build_wide_ablation.sh and build_fused96_ablation.sh build it HERE (the binaries travel to the GPU
+// box under build/labs/): the product sources, earlier versions, and sed-patched ablation variants (no DMA, no GELU, ...).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
