@@ -90,7 +90,7 @@ def stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-PRECISIONS = {"fp32": 0, "bf16": 1, "fp32_split": 2}
+PRECISIONS = {"fp32": 0, "bf16": 1, "fp32_split": 2, "bf16a": 3}
 
 
 class Context:

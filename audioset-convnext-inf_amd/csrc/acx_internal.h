@@ -69,6 +69,15 @@ constexpr size_t kCuLdsBytes = 160 * 1024;
 #define ACX_CLAIM_VGPR(n) asm volatile("" ::: "v" #n)
 #define ACX_CLAIM_AGPR(n) asm volatile("" ::: "a" #n)
 
+// ---- bf16 activations in HBM (ACX_PREC_BF16_ACT, stages 0-2): packed pairs, round to nearest even (v_cvt_pk_bf16_f32) ---
+typedef __bf16 acx_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned acx_pack_bf16x2(float lo, float hi) {
+    acx_bf2 v; v.x = (__bf16)lo; v.y = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float acx_bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float acx_bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
 struct HostTensor {
     std::vector<float> data;
     std::vector<int64_t> shape;
@@ -168,9 +177,13 @@ inline int stage_h0(int T) { return (T + 8 - 4) / 4 + 1; }
 
 // ---- kernel launchers (each returns acx_status) ---------------------------------------------
 int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s);
-int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, float* out, hipStream_t s);
-int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const float* x, float* y, float* stats, int B, int H,
-                  int W, hipStream_t s);
+// act_bf16: the activation tensors named void* are bf16 (ACX_PREC_BF16_ACT, stages 0-2) instead of fp32
+int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, void* out, hipStream_t s, bool act_bf16 = false);
+int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, float* stats, int B, int H,
+                  int W, hipStream_t s, bool act_bf16 = false);
+// element-wise fp32 <-> bf16 (the per-layer entry points of the C ABI keep fp32 tensors in every mode)
+int launch_convert_f32_to_bf16(const float* in, void* out, long long n, hipStream_t s);
+int launch_convert_bf16_to_f32(const void* in, float* out, long long n, hipStream_t s);
 int launch_rowstats(acx_ctx* c, const float* x, float* stats, int64_t M, int C, hipStream_t s);
 // out[row] = (x[row] - mean) * rstd (no affine), rows of C channels; out may alias x
 int launch_layernorm_rows(acx_ctx* c, const float* x, float* out, int64_t M, int C, hipStream_t s);
@@ -195,6 +208,7 @@ struct GemmBf16Args {
     int64_t M; int N; int Kp; int lda;
     int gather; int H, W, Cp, Ho, Wo;
     int epi; int cls;
+    int out_bf16;            // EPI_BIAS only: write the result as bf16 (the next stage's bf16 activations)
 };
 int launch_gemm_bf16(acx_ctx* c, const GemmBf16Args& a, hipStream_t s);
 // fp32 operands as two fp16 halves (gemm_split.hip): A, Wt in S16 form; EPI_GELU writes S16, the others fp32
@@ -225,8 +239,8 @@ int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, fl
 // bf16 elements) receives LayerNorm(x_new) as bf16 rows INSTEAD of x when non-null
 bool mlp_fused_wide_bf16_supported(int C);
 int mlp_fused_wide_bf16_swz(int C, int row);
-int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
-                               void* ln_out = nullptr, int ld_out = 0);
+int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const void* y, void* x, long long M, hipStream_t s,
+                               void* ln_out = nullptr, int ld_out = 0, bool act_bf16 = false);
 int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
                      hipStream_t s);
 int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, int W, int C, hipStream_t s);

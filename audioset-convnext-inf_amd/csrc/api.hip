@@ -150,6 +150,10 @@ static float hidden_scale_for(const std::vector<float>& w1, const std::vector<fl
     return std::ldexp(1.0f, e);
 }
 
+// bf16 MFMA operands (both bf16 modes); bf16 activations in HBM for the stages that keep them (ACX_PREC_BF16_ACT, stages 0-2)
+static bool is_bf16(const acx_ctx* c) { return c->precision == ACX_PREC_BF16 || c->precision == ACX_PREC_BF16_ACT; }
+static bool act_bf16(const acx_ctx* c, int stage) { return c->precision == ACX_PREC_BF16_ACT && stage >= 0 && stage < 3; }
+
 static void free_device(acx_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
@@ -264,7 +268,7 @@ static int finalize_impl(acx_ctx* c) {
         ACX_TRY(upload(c, w, &c->down[i].w));
         ACX_TRY(upload(c, b, &c->down[i].b));
         c->down[i].wh = nullptr;
-        if (c->precision == ACX_PREC_BF16) ACX_TRY(upload(c, bf16_rows(w, Co, 4, Ci, pad64(Ci)), &c->down[i].wh));
+        if (is_bf16(c)) ACX_TRY(upload(c, bf16_rows(w, Co, 4, Ci, pad64(Ci)), &c->down[i].wh));
         c->down[i].ws = nullptr;
         if (c->precision == ACX_PREC_F32_SPLIT) {
             c->down[i].ws_scale = s16_scale(w);
@@ -308,7 +312,7 @@ static int finalize_impl(acx_ctx* c) {
             }
             ACX_TRY(upload(c, f2, &bw.w2));
             ACX_TRY(upload(c, fb2, &bw.b2));
-            if (c->precision == ACX_PREC_BF16) {
+            if (is_bf16(c)) {
                 ACX_TRY(upload(c, bf16_rows(f1, 4 * C, 1, C, pad64(C)), &bw.w1h));
                 ACX_TRY(upload(c, bf16_rows(f2, C, 1, 4 * C, 4 * C), &bw.w2h));
                 if (c->use_fused_mlp && mlp_fused_wide_bf16_supported(C)) {
@@ -441,6 +445,7 @@ static int finalize_impl(acx_ctx* c) {
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+
 struct Plan {          // workspace carve-up for one forward
     int T, Hs[4], Ws[4];
     size_t off_feat, off_x[4], off_y, off_hidden, off_stats, total;
@@ -503,7 +508,7 @@ static int run_mlp_split(acx_ctx* c, const BlockW& bw, int C, float* y, float* x
 // True when the last block of stage s can hand the downsample conv its LayerNorm'ed S16 operand directly
 // (fused split MLP kernel, LNOUT epilogue): x of that stage is then NOT updated by its last block.
 static bool block_can_emit_ln(const acx_ctx* c, int s) {
-    if (s < 3 && c->precision == ACX_PREC_BF16 && c->use_fused_mlp && mlp_fused_wide_bf16_supported(kDims[s])) return true;
+    if (s < 3 && is_bf16(c) && c->use_fused_mlp && mlp_fused_wide_bf16_supported(kDims[s])) return true;
     return s < 3 && c->precision == ACX_PREC_F32_SPLIT && c->use_fused_mlp &&
            (mlp_fused_split_supported(kDims[s]) || mlp_fused_wide_supported(kDims[s]));
 }
@@ -520,9 +525,11 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
         if (ln_out) ACX_FAIL(ACX_ERR_STATE, "run_block: LayerNorm output requested from a two-GEMM stage");
         return run_mlp_split(c, bw, C, y, x, hidden, M, st);
     }
-    if (c->precision == ACX_PREC_BF16) {
-        ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
-        if (c->use_fused_mlp && bw.wstream_b) return launch_mlp_fused_wide_bf16(c, bw, C, y, x, M, st, ln_out, pad64(C));
+    if (is_bf16(c)) {
+        const bool ab = act_bf16(c, s);         // x and y of this stage are bf16 tensors in HBM
+        ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st, ab));
+        if (c->use_fused_mlp && bw.wstream_b) return launch_mlp_fused_wide_bf16(c, bw, C, y, x, M, st, ln_out, pad64(C), ab);
+        if (ab) ACX_FAIL(ACX_ERR_STATE, "run_block: bf16 activations need the fused block kernel (stage %d)", s);
         if (ln_out) ACX_FAIL(ACX_ERR_STATE, "run_block: LayerNorm output requested from a two-GEMM stage");
         return run_mlp_bf16(c, bw, C, y, x, hidden, M, st);
     }
@@ -543,8 +550,10 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
 }
 
 // have_ln: xnorm already holds the normalised S16 rows (written by the last block of the previous stage)
+// out_bf16: the result is the bf16 activation tensor of stage i (ACX_PREC_BF16_ACT inside acx_forward; the per-layer entry
+// point keeps fp32)
 static int run_downsample(acx_ctx* c, int i, const float* x, float* out, float* xnorm, int B, int H, int Wd,
-                          hipStream_t st, bool have_ln = false) {
+                          hipStream_t st, bool have_ln = false, bool out_bf16 = false) {
     const int Ci = kDims[i - 1], Co = kDims[i];
     if (c->precision == ACX_PREC_F32_SPLIT) {
         if (!have_ln) ACX_TRY(launch_layernorm_rows_split(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
@@ -555,10 +564,11 @@ static int run_downsample(acx_ctx* c, int i, const float* x, float* out, float* 
         g.epi = EPI_BIAS; g.cls = ACX_K_DOWNSAMPLE;
         return launch_gemm_split(c, g, st);
     }
-    if (c->precision == ACX_PREC_BF16) {
+    if (is_bf16(c)) {
         const int Cp = pad64(Ci);
         if (!have_ln) ACX_TRY(launch_layernorm_rows_bf16(c, x, xnorm, (int64_t)B * H * Wd, Ci, st));
         GemmBf16Args g{};
+        g.out_bf16 = out_bf16 ? 1 : 0;
         g.A = xnorm; g.Wt = c->down[i].wh; g.bias = c->down[i].b; g.out = out;
         g.gather = 1; g.H = H; g.W = Wd; g.Cp = Cp; g.Ho = H / 2; g.Wo = Wd / 2;
         g.M = (int64_t)B * g.Ho * g.Wo; g.N = Co; g.Kp = 4 * Cp; g.lda = Cp; g.epi = EPI_BIAS; g.cls = ACX_K_DOWNSAMPLE;
@@ -683,7 +693,7 @@ int acx_finalize(acx_ctx* c) {
 
 int acx_set_precision(acx_ctx* c, int precision) {
     if (!c) ACX_FAIL(ACX_ERR_ARG, "null context");
-    if (precision != ACX_PREC_F32 && precision != ACX_PREC_BF16 && precision != ACX_PREC_F32_SPLIT) ACX_FAIL(ACX_ERR_ARG, "acx_set_precision: unknown precision %d", precision);
+    if (precision != ACX_PREC_F32 && precision != ACX_PREC_BF16 && precision != ACX_PREC_F32_SPLIT && precision != ACX_PREC_BF16_ACT) ACX_FAIL(ACX_ERR_ARG, "acx_set_precision: unknown precision %d", precision);
     if (precision != c->precision) { c->precision = precision; c->finalized = false; }
     return ACX_OK;
 }
@@ -751,7 +761,7 @@ static int forward_one(acx_ctx* c, const float* wav, int B, int64_t L, int mode,
     float* stats = (float*)(ws + p.off_stats);
 
     ACX_TRY(launch_logmel(c, wav, B, L, p.T, feat, true, st));
-    ACX_TRY(launch_stem(c, feat, B, p.T, p.Hs[0], x[0], st));
+    ACX_TRY(launch_stem(c, feat, B, p.T, p.Hs[0], x[0], st, act_bf16(c, 0)));
     for (int s = 0; s < 4; ++s) {
         // The last block of stages 0-2 writes LayerNorm(x) as GEMM operand rows (S16 / bf16) instead of x: nothing else
         // reads that x (convnext.py:270-273).  The rows go to the `hidden` scratch (idle in the fused stages), never to
@@ -759,7 +769,8 @@ static int forward_one(acx_ctx* c, const float* wav, int B, int64_t L, int mode,
         // than the fp32 rows they would overwrite.
         if (s > 0) {
             const bool have_ln = block_can_emit_ln(c, s - 1);
-            ACX_TRY(run_downsample(c, s, x[s - 1], x[s], have_ln ? hidden : y, B, p.Hs[s - 1], p.Ws[s - 1], st, have_ln));
+            if (act_bf16(c, s - 1) && !have_ln) ACX_FAIL(ACX_ERR_STATE, "bf16 activations: stage %d must hand its LayerNorm rows to the downsample conv", s - 1);
+            ACX_TRY(run_downsample(c, s, x[s - 1], x[s], have_ln ? hidden : y, B, p.Hs[s - 1], p.Ws[s - 1], st, have_ln, act_bf16(c, s)));
         }
         for (int j = 0; j < kDepths[s]; ++j) {
             void* ln_out = (j == kDepths[s] - 1 && block_can_emit_ln(c, s)) ? (void*)hidden : nullptr;
@@ -852,6 +863,14 @@ int acx_block(acx_ctx* c, int stage, int block, float* x, int B, int H, int Wd, 
     float* y = (float*)ws;
     float* hidden = (float*)(ws + align_up(pix * kDims[stage] * 4));
     float* stats = (float*)(ws + align_up(pix * kDims[stage] * 4) + align_up(pix * 4 * kDims[stage] * 4));
+    if (act_bf16(c, stage)) {
+        // The ABI keeps fp32 tensors; the block itself runs on bf16 activations: x is rounded to bf16 into the (otherwise idle)
+        // hidden scratch, dwconv + fused MLP read and write bf16 there, and the result is widened back into x.
+        const long long n = (long long)pix * kDims[stage];
+        ACX_TRY(launch_convert_f32_to_bf16(x, hidden, n, (hipStream_t)stream));
+        ACX_TRY(run_block(c, stage, block, hidden, y, hidden, stats, B, H, Wd, (hipStream_t)stream));
+        return launch_convert_bf16_to_f32(hidden, x, n, (hipStream_t)stream);
+    }
     return run_block(c, stage, block, x, y, hidden, stats, B, H, Wd, (hipStream_t)stream);
 }
 

@@ -9,6 +9,8 @@
 // registers; an input row (13 LDS reads) feeds both output rows, a kernel row's 7 weights are read once for the
 // pair.  The input rows and the 49x32 weight slice are staged through LDS; the batch is streamed as ONE tall
 // image (see the kernel), every input element is fetched from HBM once per column strip.
+#include <type_traits>
+
 #include "acx_internal.h"
 
 namespace acx {
@@ -26,7 +28,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // into the ring slots of the TH oldest rows after them), so every input row is fetched once per strip
 // (the first tile-only version re-read its 6 halo rows per tile: FETCH_SIZE 1.93x the algorithmic bytes,
 // profiles/r01_c_pmc_per_kernel.csv) and HBM latency hides under the arithmetic.
-template <int TW, int TH>
+// BF: x and y are bf16 in HBM (ACX_PREC_BF16_ACT, stages 0-2): a 16-byte load carries 8 channels (a pixel's 32-channel
+// slice is 64 bytes), widened to fp32 on its way into the LDS ring; outputs are rounded to bf16 (nearest even) when they
+// leave.  Ring, weights, bias and all arithmetic stay fp32.
+template <int TW, int TH, bool BF = false>
 struct DwCfg {
     static constexpr int WT = 7;
     static constexpr int kStrips = TW / WT;
@@ -34,18 +39,23 @@ struct DwCfg {
     static constexpr int kCols = TW + 6;
     static constexpr int kRing = TH + 6;
     static constexpr int kRowF4 = kCols * 8;                      // float4 per ring row
-    static constexpr int kStepF4 = TH * kRowF4;                   // float4 fetched per step
-    static constexpr int kStage = (kStepF4 + kThreads - 1) / kThreads;   // staging float4 per thread
+    static constexpr int kEPV = BF ? 8 : 4;                       // tensor elements per 16-byte load
+    static constexpr int kQ = kDwSlice / kEPV;                    // 16-byte loads per pixel slice
+    static constexpr int kStepF4 = TH * kCols * kQ;               // 16-byte loads fetched per step
+    static constexpr int kStage = (kStepF4 + kThreads - 1) / kThreads;   // staging loads per thread
     static constexpr size_t kLdsBytes = (size_t)(kRing * kRowF4 + 49 * 8 + 256) * 16;   // ring + weights + sinks
 };
 
-template <int TW, int TH>
-__global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <int TW, int TH, bool BF>
+__global__ __launch_bounds__(256, 2) void dwconv7_kernel(const void* __restrict__ x_, void* __restrict__ y_,
                                                          const float* __restrict__ wt /*[49][C]*/,
                                                          const float* __restrict__ bias, int B, int H, int W,
                                                          int C, int tiles_w, int tiles_h, int n_seg,
                                                          unsigned magic /* floor(2^32 / (H + 3)) + 1 */) {
-    using Cfg = DwCfg<TW, TH>;
+    using Cfg = DwCfg<TW, TH, BF>;
+    using T = typename std::conditional<BF, __bf16, float>::type;
+    const T* __restrict__ x = reinterpret_cast<const T*>(x_);
+    T* __restrict__ y = reinterpret_cast<T*>(y_);
     static_assert(Cfg::kThreads == 256, "thread mapping assumes 256 threads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* ring = reinterpret_cast<f32x4*>(smem);                  // [kRing][kCols][8]
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
         if (i >= 49 * 8) i = 49 * 8 - 1;
         wreg[k] = *reinterpret_cast<const f32x4*>(wt + (i >> 3) * C + c0 + 4 * (i & 7));
     }
-    const float* xb = x + c0;
+    const T* xb = x + c0;
     // The B images of the batch form ONE tall virtual image: H rows of clip 0, 3 rows of zeros, H rows of clip 1,
     // ... (3 zero rows are all the 7x7 window ever sees between two clips, and consecutive clips are
     // consecutive in memory), so the ring streams straight through the batch and a workgroup lives for many
@@ -96,20 +106,20 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
     // Loads are UNCONDITIONAL on valid addresses (a per-element "load or zero" makes hipcc branch around every
     // load and wait for all of them on the spot); rows outside the image only occur in the first/last step of a
     // column and take the slow (clamp + zero) path, selected by a wave-uniform test.
-    const float* st_ptr[Cfg::kStage];
+    const T* st_ptr[Cfg::kStage];
     int st_row[Cfg::kStage], st_lds[Cfg::kStage];
 #pragma unroll
     for (int k = 0; k < Cfg::kStage; ++k) {
         int i = tid + k * Cfg::kThreads;
         const bool in_step = i < Cfg::kStepF4;
         if (!in_step) i = Cfg::kStepF4 - 1;
-        const int qq = i & 7;
-        const int col = (i >> 3) % Cfg::kCols;
-        st_row[k] = (i >> 3) / Cfg::kCols;
+        const int qq = i % Cfg::kQ;
+        const int col = (i / Cfg::kQ) % Cfg::kCols;
+        st_row[k] = (i / Cfg::kQ) / Cfg::kCols;
         const int gw = w0 - 3 + col;
         const int gwc = gw < 0 ? 0 : (gw >= W ? W - 1 : gw);
-        st_ptr[k] = xb + st_row[k] * row_elems + gwc * C + 4 * qq;
-        st_lds[k] = (in_step && gw >= 0 && gw < W) ? (col * 8 + qq) : -1;
+        st_ptr[k] = xb + st_row[k] * row_elems + gwc * C + Cfg::kEPV * qq;
+        st_lds[k] = (in_step && gw >= 0 && gw < W) ? (col * 8 + qq * (8 / Cfg::kQ)) : -1;     // BF: two float4 from here
     }
     const int g_origin = t_begin * TH - 3;             // image row kept in ring row 0 of this segment
     f32x4 rg[Cfg::kStage];
@@ -140,7 +150,13 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
                 if (!ok_) v = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
             }                                                                                             \
             f32x4* dst = keep ? ring + slot * Cfg::kRowF4 + st_lds[k] : dummy + tid;                      \
-            *dst = v;                                                                                     \
+            if (BF) {                               /* 8 bf16 -> two float4 (channels 8 qq .. 8 qq + 7) */   \
+                const uint4 u_ = __builtin_bit_cast(uint4, v);                                            \
+                dst[0] = f32x4{acx_bf16_lo(u_.x), acx_bf16_hi(u_.x), acx_bf16_lo(u_.y), acx_bf16_hi(u_.y)};   \
+                (keep ? dst + 1 : dst)[0] = f32x4{acx_bf16_lo(u_.z), acx_bf16_hi(u_.z), acx_bf16_lo(u_.w), acx_bf16_hi(u_.w)}; \
+            } else {                                                                                      \
+                *dst = v;                                                                                 \
+            }                                                                                             \
         }                                                                                                 \
     }
 #define ACX_DW_STORE(first_row, max_rows, edge) ACX_DW_STORE_FROM(rg, first_row, max_rows, edge)
@@ -175,13 +191,15 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const float* __restrict
     constexpr int kRowF2 = Cfg::kRowF4 * 2;
     const f32x2 bv = *reinterpret_cast<const f32x2*>(bias + c0 + 2 * l16);
     const int rd_off = (strip * Cfg::WT) * 16 + l16;   // float2 offset of this thread's first input column
-    float* const yb = y + (long long)(w0 + strip * Cfg::WT) * C + c0 + 2 * l16;
+    T* const yb = y + (long long)(w0 + strip * Cfg::WT) * C + c0 + 2 * l16;
 
     f32x2 so0[Cfg::WT], so1[Cfg::WT];
 #pragma unroll
     for (int i = 0; i < Cfg::WT; ++i) so0[i] = so1[i] = bv;
-    float *yp0 = nullptr, *yp1 = nullptr;              // where so0[] / so1[] belong (null: nothing pending)
-#define ACX_DW_FLUSH1(yp_, so_) if (yp_ != nullptr) { _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) *reinterpret_cast<f32x2*>(yp_ + (long long)i * C) = so_[i]; }
+    T *yp0 = nullptr, *yp1 = nullptr;                  // where so0[] / so1[] belong (null: nothing pending)
+#define ACX_DW_FLUSH1(yp_, so_) if (yp_ != nullptr) { _Pragma("unroll") for (int i = 0; i < Cfg::WT; ++i) {         \
+        if (BF) *reinterpret_cast<unsigned*>(yp_ + (long long)i * C) = acx_pack_bf16x2(so_[i].x, so_[i].y);           \
+        else *reinterpret_cast<f32x2*>(yp_ + (long long)i * C) = so_[i]; } }
 #define ACX_DW_FLUSH ACX_DW_FLUSH1(yp0, so0) ACX_DW_FLUSH1(yp1, so1)
     for (int t = t_begin; t < t_end; ++t) {
         const int h0 = t * TH;
@@ -446,21 +464,21 @@ int launch_layernorm_rows_bf16(acx_ctx* c, const float* x, void* out, int64_t M,
     return launch_rows<2>(c, x, reinterpret_cast<float*>(out), M, C, s);
 }
 
-template <int TW, int TH>
-static int launch_dw_cfg(const BlockW& w, int C, const float* x, float* y, int B, int H, int W, hipStream_t s) {
+template <int TW, int TH, bool BF>
+static int launch_dw_cfg(const BlockW& w, int C, const void* x, void* y, int B, int H, int W, hipStream_t s) {
     // exactness of v / (H + 3) by multiply-high needs (stacked rows) * (H + 3) < 2^32: longer batches in chunks
     const long long max_b = (0xffffffffll / (H + 3)) / (H + 3);
     if (B > max_b) {
         for (long long b0 = 0; b0 < B; b0 += max_b) {
             const int nb = (int)((B - b0) < max_b ? (B - b0) : max_b);
-            const long long off = b0 * (long long)H * W * C;
-            ACX_TRY((launch_dw_cfg<TW, TH>(w, C, x + off, y + off, nb, H, W, s)));
+            const long long off = b0 * (long long)H * W * C * (BF ? 2 : 4);
+            ACX_TRY((launch_dw_cfg<TW, TH, BF>(w, C, reinterpret_cast<const char*>(x) + off, reinterpret_cast<char*>(y) + off, nb, H, W, s)));
         }
         return ACX_OK;
     }
-    using Cfg = DwCfg<TW, TH>;
+    using Cfg = DwCfg<TW, TH, BF>;
     static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &dwconv7_kernel<TW, TH>, Cfg::kLdsBytes));
+    ACX_TRY(set_max_dynamic_lds(once, &dwconv7_kernel<TW, TH, BF>, Cfg::kLdsBytes));
     const int Hv = B * (H + 3) - 3;                    // stacked rows (no gap after the last clip)
     const int tiles_w = W / TW, tiles_h = (Hv + TH - 1) / TH;
     const long long columns = (long long)tiles_w * (C / kDwSlice);
@@ -472,27 +490,28 @@ static int launch_dw_cfg(const BlockW& w, int C, const float* x, float* y, int B
     if (n_seg > tiles_h / 2) n_seg = tiles_h / 2;
     if (n_seg < 1) n_seg = 1;
     const long long blocks = columns * n_seg;
-    dwconv7_kernel<TW, TH><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(
+    dwconv7_kernel<TW, TH, BF><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(
         x, y, w.dw, w.dwb, B, H, W, C, tiles_w, tiles_h, n_seg, (unsigned)(0x100000000ull / (unsigned)(H + 3)) + 1u);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
 
-int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const float* x, float* y, float* stats, int B, int H,
-                  int W, hipStream_t s) {
+int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, float* stats, int B, int H,
+                  int W, hipStream_t s, bool act_bf16) {
+    if (act_bf16 && stats) ACX_FAIL(ACX_ERR_STATE, "dwconv7: row statistics are computed from fp32 activations only");
     {
         ProfScope ps(c, ACX_K_DWCONV, s);
         int rc;
         switch (W) {
-            case 56: rc = launch_dw_cfg<28, 8>(w, C, x, y, B, H, W, s); break;
-            case 28: rc = launch_dw_cfg<28, 8>(w, C, x, y, B, H, W, s); break;
-            case 14: rc = launch_dw_cfg<14, 16>(w, C, x, y, B, H, W, s); break;
-            case 7: rc = launch_dw_cfg<7, 32>(w, C, x, y, B, H, W, s); break;   // 31x7 image: one step
+            case 56: rc = act_bf16 ? launch_dw_cfg<28, 8, true>(w, C, x, y, B, H, W, s) : launch_dw_cfg<28, 8, false>(w, C, x, y, B, H, W, s); break;
+            case 28: rc = act_bf16 ? launch_dw_cfg<28, 8, true>(w, C, x, y, B, H, W, s) : launch_dw_cfg<28, 8, false>(w, C, x, y, B, H, W, s); break;
+            case 14: rc = act_bf16 ? launch_dw_cfg<14, 16, true>(w, C, x, y, B, H, W, s) : launch_dw_cfg<14, 16, false>(w, C, x, y, B, H, W, s); break;
+            case 7: rc = act_bf16 ? launch_dw_cfg<7, 32, true>(w, C, x, y, B, H, W, s) : launch_dw_cfg<7, 32, false>(w, C, x, y, B, H, W, s); break;   // 31x7 image: one step
             default: ACX_FAIL(ACX_ERR_SHAPE, "dwconv7: unsupported width %d (expected 56/28/14/7)", W);
         }
         ACX_TRY(rc);
     }
-    if (stats) ACX_TRY(launch_rowstats(c, y, stats, (int64_t)B * H * W, C, s));
+    if (stats) ACX_TRY(launch_rowstats(c, reinterpret_cast<const float*>(y), stats, (int64_t)B * H * W, C, s));
     return ACX_OK;
 }
 

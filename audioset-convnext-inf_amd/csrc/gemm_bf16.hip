@@ -43,7 +43,8 @@ __device__ __forceinline__ void lds_dma16_b(const __bf16* gsrc, char* lds_wave_b
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// EPI: 0 bias -> fp32, 1 bias + GELU -> bf16, 2 bias + residual -> fp32
+// EPI: 0 bias -> fp32, 1 bias + GELU -> bf16, 2 bias + residual -> fp32, 3 bias -> bf16 (the downsample conv feeding a stage
+// whose activations live in HBM as bf16: ACX_PREC_BF16_ACT)
 template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p) {
     constexpr int TM = kBM / (WM * 32);
@@ -223,6 +224,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
                     float v = acc[i][j][r] + bn;
                     if (EPI == 1) {
                         reinterpret_cast<__bf16*>(p.out)[off] = (__bf16)gelu_erf_b(v);
+                    } else if (EPI == 3) {
+                        reinterpret_cast<__bf16*>(p.out)[off] = (__bf16)v;
                     } else {
                         if (EPI == 2) v += p.resid[off];
                         reinterpret_cast<float*>(p.out)[off] = v;
@@ -266,8 +269,9 @@ int launch_gemm_bf16(acx_ctx* c, const GemmBf16Args& a, hipStream_t s) {
     ProfScope ps(c, a.cls, s);
     if (a.gather) {
         if (a.epi != EPI_BIAS || a.Cp % kBfBK != 0) ACX_FAIL(ACX_ERR_ARG, "gemm_bf16: bad gather configuration");
-        return launch_bf_bn<0, 1>(p, s);
+        return a.out_bf16 ? launch_bf_bn<3, 1>(p, s) : launch_bf_bn<0, 1>(p, s);
     }
+    if (a.out_bf16) ACX_FAIL(ACX_ERR_ARG, "gemm_bf16: bf16 output exists for the gather (downsample) form only");
     if (a.epi == EPI_GELU) return launch_bf_bn<1, 0>(p, s);
     if (a.epi == EPI_RESID) return launch_bf_bn<2, 0>(p, s);
     if (a.epi == EPI_BIAS) return launch_bf_bn<0, 0>(p, s);

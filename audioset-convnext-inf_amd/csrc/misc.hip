@@ -132,4 +132,37 @@ int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, in
     return ACX_OK;
 }
 
+// element-wise fp32 <-> bf16 (round to nearest even): the per-layer entry points of the C ABI keep fp32 tensors in every mode
+// and convert at their boundary when the activations live in HBM as bf16 (ACX_PREC_BF16_ACT)
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        reinterpret_cast<uint2*>(out)[i] = uint2{acx_pack_bf16x2(v.x, v.y), acx_pack_bf16x2(v.z, v.w)};
+    }
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const __bf16* __restrict__ in, float* __restrict__ out, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const uint2 u = reinterpret_cast<const uint2*>(in)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(acx_bf16_lo(u.x), acx_bf16_hi(u.x), acx_bf16_lo(u.y), acx_bf16_hi(u.y));
+    }
+}
+int launch_convert_f32_to_bf16(const float* in, void* out, long long n, hipStream_t s) {
+    if (n % 4 != 0) ACX_FAIL(ACX_ERR_SHAPE, "convert: %lld elements (not a multiple of 4)", n);
+    const long long n4 = n / 4;
+    if (n4 == 0) return ACX_OK;
+    const long long blocks = (n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096;
+    f32_to_bf16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, reinterpret_cast<__bf16*>(out), n4);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+int launch_convert_bf16_to_f32(const void* in, float* out, long long n, hipStream_t s) {
+    if (n % 4 != 0) ACX_FAIL(ACX_ERR_SHAPE, "convert: %lld elements (not a multiple of 4)", n);
+    const long long n4 = n / 4;
+    if (n4 == 0) return ACX_OK;
+    const long long blocks = (n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096;
+    bf16_to_f32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(reinterpret_cast<const __bf16*>(in), out, n4);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
 }  // namespace acx

@@ -48,9 +48,38 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
-template <int C, int PT, bool LNOUT>
+// ABF: y and x are bf16 in HBM (ACX_PREC_BF16_ACT): 8 channels per 16-byte load, 4 per 8-byte load / store; everything between
+// the loads and the stores is unchanged (fp32 LayerNorm statistics, fp32 accumulate, fp32 GELU, fp32 residual add)
+template <bool ABF>
+__device__ __forceinline__ void acx_ld8(const void* base, long long off, float* o) {        // 8 consecutive channels
+    if constexpr (ABF) {
+        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + off);
+        o[0] = acx_bf16_lo(u.x); o[1] = acx_bf16_hi(u.x); o[2] = acx_bf16_lo(u.y); o[3] = acx_bf16_hi(u.y);
+        o[4] = acx_bf16_lo(u.z); o[5] = acx_bf16_hi(u.z); o[6] = acx_bf16_lo(u.w); o[7] = acx_bf16_hi(u.w);
+    } else {
+        const float4 v0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+        const float4 v1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off + 4);
+        o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+    }
+}
+template <bool ABF>
+__device__ __forceinline__ float4 acx_ld4(const void* base, long long off) {                 // 4 consecutive channels
+    if constexpr (ABF) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(base) + off);
+        return make_float4(acx_bf16_lo(u.x), acx_bf16_hi(u.x), acx_bf16_lo(u.y), acx_bf16_hi(u.y));
+    } else {
+        return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+    }
+}
+template <bool ABF>
+__device__ __forceinline__ void acx_st4(void* base, long long off, float4 v) {
+    if constexpr (ABF) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(base) + off) = uint2{acx_pack_bf16x2(v.x, v.y), acx_pack_bf16x2(v.z, v.w)};
+    else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off) = v;
+}
+
+template <int C, int PT, bool LNOUT, bool ABF>
 __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
-    const float* __restrict__ y, float* __restrict__ x, const char* __restrict__ wstream /*[2n][128 C bytes]*/,
+    const void* __restrict__ y, void* __restrict__ x, const char* __restrict__ wstream /*[2n][128 C bytes]*/,
     const float* __restrict__ b1, const float* __restrict__ b2, long long M, int ld_out,
     __bf16* __restrict__ ln_out /* LNOUT: (M, ld_out) bf16 rows of LayerNorm(x_new), written INSTEAD of x */) {
     using Cfg = WideBfCfg<C, PT>;
@@ -89,14 +118,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         float a[C / 2];
-        const float* yp = y + mrow[pt] * C + 8 * hh;
 #pragma unroll
-        for (int s = 0; s < Cfg::kSteps; ++s) {
-            const float4 v0 = *reinterpret_cast<const float4*>(yp + 16 * s);
-            const float4 v1 = *reinterpret_cast<const float4*>(yp + 16 * s + 4);
-            a[8 * s + 0] = v0.x; a[8 * s + 1] = v0.y; a[8 * s + 2] = v0.z; a[8 * s + 3] = v0.w;
-            a[8 * s + 4] = v1.x; a[8 * s + 5] = v1.y; a[8 * s + 6] = v1.z; a[8 * s + 7] = v1.w;
-        }
+        for (int s = 0; s < Cfg::kSteps; ++s) acx_ld8<ABF>(y, mrow[pt] * C + 8 * hh + 16 * s, a + 8 * s);
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < C / 2; ++i) sum += a[i];
@@ -261,11 +284,10 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     float4 xr[PT][C / 8];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-        const float* xp = x + mrow[pt] * C + 4 * hh;
 #pragma unroll
         for (int t = 0; t < Cfg::kTiles; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xr[pt][4 * t + q] = *reinterpret_cast<const float4*>(xp + 32 * t + 8 * q);
+            for (int q = 0; q < 4; ++q) xr[pt][4 * t + q] = acx_ld4<ABF>(x, mrow[pt] * C + 4 * hh + 32 * t + 8 * q);
     }
     phase2(std::true_type{}, 2 * n - 2, grp);
     grp = grp == 2 ? 0 : grp + 1;
@@ -329,7 +351,6 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
                     *reinterpret_cast<uint2*>(ln_out + mrow[pt] * (long long)ld_out + c) = uint2{0u, 0u};
             }
         } else if (valid[pt]) {
-            float* xp = x + mrow[pt] * C + 4 * hh;
 #pragma unroll
             for (int t = 0; t < Cfg::kTiles; ++t)
 #pragma unroll
@@ -341,20 +362,20 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
                     v.y += acc[pt][t][4 * q + 1] + bb.y;
                     v.z += acc[pt][t][4 * q + 2] + bb.z;
                     v.w += acc[pt][t][4 * q + 3] + bb.w;
-                    *reinterpret_cast<float4*>(xp + c) = v;
+                    acx_st4<ABF>(x, mrow[pt] * C + 4 * hh + c, v);
                 }
         }
     }
 }
 
-template <int C, int PT, bool LNOUT>
-static int launch_wide_bf16_cfg(const BlockW& w, const float* y, float* x, long long M, void* ln_out, int ld_out, hipStream_t s) {
+template <int C, int PT, bool LNOUT, bool ABF>
+static int launch_wide_bf16_cfg(const BlockW& w, const void* y, void* x, long long M, void* ln_out, int ld_out, hipStream_t s) {
     using Cfg = WideBfCfg<C, PT>;
     static_assert(Cfg::kLdsBytes <= kCuLdsBytes, "weight ring does not fit the LDS");
     static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_bf16_kernel<C, PT, LNOUT>, kCuLdsBytes));
+    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_bf16_kernel<C, PT, LNOUT, ABF>, kCuLdsBytes));
     const long long blocks = (M + Cfg::kPix - 1) / Cfg::kPix;
-    mlp_fused_wide_bf16_kernel<C, PT, LNOUT><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s>>>(
+    mlp_fused_wide_bf16_kernel<C, PT, LNOUT, ABF><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s>>>(
         y, x, reinterpret_cast<const char*>(w.wstream_b), w.b1, w.b2, M, ld_out, reinterpret_cast<__bf16*>(ln_out));
     ACX_HIP(hipGetLastError());
     return ACX_OK;
@@ -369,9 +390,9 @@ static int launch_wide_bf16_cfg(const BlockW& w, const float* y, float* x, long 
 // spread over all phases, memory latency hides behind the other waves' matrix and vector work, and the per-segment
 // barrier and LDS-DMA issue are gone.  Same stream layout (api.hip packs one `wstream_b` for both kernels), same
 // arithmetic and rounding points.
-template <bool LNOUT>
+template <bool LNOUT, bool ABF>
 __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
-    const float* __restrict__ y, float* __restrict__ x, const char* __restrict__ wstream /*[12][12288 B]*/,
+    const void* __restrict__ y, void* __restrict__ x, const char* __restrict__ wstream /*[12][12288 B]*/,
     const float* __restrict__ b1, const float* __restrict__ b2, long long M, int ld_out, __bf16* __restrict__ ln_out) {
     constexpr int C = 96;
     using Cfg = WideBfCfg<C, 1>;
@@ -417,12 +438,17 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
     const long long ntiles = (M + 31) / 32;
     const long long tstride = (long long)gridDim.x * 8;
     // software pipeline over the wave's tiles: the y rows of tile i + 1 are requested before the chunks of tile i start
-    float4 yn[C / 8];
+    // (raw 16-byte loads: fp32 two per k-step, bf16 one)
+    float4 yn[ABF ? C / 16 : C / 8];
 #define ACX_LOAD_Y(tile_)                                                                                       \
     {   long long r_ = (tile_) * 32 + l31; if (r_ >= M) r_ = M - 1;                                             \
-        const float* yp_ = y + r_ * C + 8 * hh;                                                                 \
-        _Pragma("unroll") for (int s = 0; s < Cfg::kSteps; ++s) {                                               \
-            yn[2 * s] = *reinterpret_cast<const float4*>(yp_ + 16 * s); yn[2 * s + 1] = *reinterpret_cast<const float4*>(yp_ + 16 * s + 4); } }
+        if constexpr (ABF) {                                                                                    \
+            const __bf16* yp_ = reinterpret_cast<const __bf16*>(y) + r_ * C + 8 * hh;                           \
+            _Pragma("unroll") for (int s = 0; s < Cfg::kSteps; ++s) yn[s] = *reinterpret_cast<const float4*>(yp_ + 16 * s); \
+        } else {                                                                                                \
+            const float* yp_ = reinterpret_cast<const float*>(y) + r_ * C + 8 * hh;                             \
+            _Pragma("unroll") for (int s = 0; s < Cfg::kSteps; ++s) {                                           \
+                yn[2 * s] = *reinterpret_cast<const float4*>(yp_ + 16 * s); yn[2 * s + 1] = *reinterpret_cast<const float4*>(yp_ + 16 * s + 4); } } }
     long long tile = (long long)blockIdx.x * 8 + wave;
     if (tile < ntiles) ACX_LOAD_Y(tile)
     for (; tile < ntiles; tile += tstride) {
@@ -433,8 +459,17 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
         f32x4 act[Cfg::kSteps];
         {
             float a[C / 2];
+            if constexpr (ABF) {
 #pragma unroll
-            for (int i = 0; i < C / 8; ++i) { a[4 * i] = yn[i].x; a[4 * i + 1] = yn[i].y; a[4 * i + 2] = yn[i].z; a[4 * i + 3] = yn[i].w; }
+                for (int i = 0; i < C / 16; ++i) {
+                    const uint4 u = __builtin_bit_cast(uint4, yn[i]);
+                    a[8 * i + 0] = acx_bf16_lo(u.x); a[8 * i + 1] = acx_bf16_hi(u.x); a[8 * i + 2] = acx_bf16_lo(u.y); a[8 * i + 3] = acx_bf16_hi(u.y);
+                    a[8 * i + 4] = acx_bf16_lo(u.z); a[8 * i + 5] = acx_bf16_hi(u.z); a[8 * i + 6] = acx_bf16_lo(u.w); a[8 * i + 7] = acx_bf16_hi(u.w);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < C / 8; ++i) { a[4 * i] = yn[i].x; a[4 * i + 1] = yn[i].y; a[4 * i + 2] = yn[i].z; a[4 * i + 3] = yn[i].w; }
+            }
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < C / 2; ++i) sum += a[i];
@@ -456,11 +491,10 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
         // the residual rows: in flight while the chunks run
         float4 xr[C / 8];
         {
-            const float* xp = x + mrow * C + 4 * hh;
 #pragma unroll
             for (int t = 0; t < Cfg::kTiles; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xr[4 * t + q] = *reinterpret_cast<const float4*>(xp + 32 * t + 8 * q);
+                for (int q = 0; q < 4; ++q) xr[4 * t + q] = acx_ld4<ABF>(x, mrow * C + 4 * hh + 32 * t + 8 * q);
         }
         if (tile + tstride < ntiles) ACX_LOAD_Y(tile + tstride)
         f32x16 acc[Cfg::kTiles];
@@ -547,7 +581,6 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
                     *reinterpret_cast<uint2*>(ln_out + mrow * (long long)ld_out + c) = uint2{0u, 0u};
             }
         } else if (valid) {
-            float* xp = x + mrow * C + 4 * hh;
 #pragma unroll
             for (int t = 0; t < Cfg::kTiles; ++t)
 #pragma unroll
@@ -559,7 +592,7 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
                     v.y += acc[t][4 * q + 1] + bb.y;
                     v.z += acc[t][4 * q + 2] + bb.z;
                     v.w += acc[t][4 * q + 3] + bb.w;
-                    *reinterpret_cast<float4*>(xp + c) = v;
+                    acx_st4<ABF>(x, mrow * C + 4 * hh + c, v);
                 }
         }
     }
@@ -582,14 +615,14 @@ static int cu_count() {
     return v;
 }
 
-template <bool LNOUT>
-static int launch_stat_bf16(const BlockW& w, const float* y, float* x, long long M, void* ln_out, int ld_out, hipStream_t s) {
+template <bool LNOUT, bool ABF>
+static int launch_stat_bf16(const BlockW& w, const void* y, void* x, long long M, void* ln_out, int ld_out, hipStream_t s) {
     static_assert(WideBfCfg<96, 1>::kSegs * WideBfCfg<96, 1>::kSegBytes + 5 * 96 * 4 <= kCuLdsBytes, "stream does not fit the LDS");
     static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_stat_bf16_kernel<LNOUT>, kCuLdsBytes));
+    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_stat_bf16_kernel<LNOUT, ABF>, kCuLdsBytes));
     const long long wgs_needed = ((M + 31) / 32 + 7) / 8;
     const long long blocks = wgs_needed < cu_count() ? wgs_needed : cu_count();
-    mlp_fused_stat_bf16_kernel<LNOUT><<<dim3((unsigned)blocks), dim3(512), kCuLdsBytes /* CU-exclusive */, s>>>(
+    mlp_fused_stat_bf16_kernel<LNOUT, ABF><<<dim3((unsigned)blocks), dim3(512), kCuLdsBytes /* CU-exclusive */, s>>>(
         y, x, reinterpret_cast<const char*>(w.wstream_b), w.b1, w.b2, M, ld_out, reinterpret_cast<__bf16*>(ln_out));
     ACX_HIP(hipGetLastError());
     return ACX_OK;
@@ -602,14 +635,19 @@ int mlp_fused_wide_bf16_swz(int C, int row) {
     return C == 384 ? WideBfCfg<384, 1>::swz1(row) : (C == 192 ? WideBfCfg<192, 1>::swz1(row) : WideBfCfg<96, 1>::swz1(row));
 }
 
-int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s,
-                               void* ln_out, int ld_out) {
+template <bool ABF>
+static int launch_bf16_any(const BlockW& w, int C, const void* y, void* x, long long M, hipStream_t s, void* ln_out, int ld_out) {
+    if (C == 384) return ln_out ? launch_wide_bf16_cfg<384, 1, true, ABF>(w, y, x, M, ln_out, ld_out, s) : launch_wide_bf16_cfg<384, 1, false, ABF>(w, y, x, M, nullptr, 0, s);
+    if (C == 192) return ln_out ? launch_wide_bf16_cfg<192, 1, true, ABF>(w, y, x, M, ln_out, ld_out, s) : launch_wide_bf16_cfg<192, 1, false, ABF>(w, y, x, M, nullptr, 0, s);
+    if (C == 96) return ln_out ? launch_stat_bf16<true, ABF>(w, y, x, M, ln_out, ld_out, s) : launch_stat_bf16<false, ABF>(w, y, x, M, nullptr, 0, s);
+    ACX_FAIL(ACX_ERR_SHAPE, "fused bf16 MLP: unsupported channel count %d", C);
+}
+
+int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const void* y, void* x, long long M, hipStream_t s,
+                               void* ln_out, int ld_out, bool act_bf16) {
     if (!w.wstream_b) ACX_FAIL(ACX_ERR_STATE, "fused bf16 MLP: the weight stream was not packed for C=%d", C);
     ProfScope ps(c, ACX_K_MLP_WIDE, s);
-    if (C == 384) return ln_out ? launch_wide_bf16_cfg<384, 1, true>(w, y, x, M, ln_out, ld_out, s) : launch_wide_bf16_cfg<384, 1, false>(w, y, x, M, nullptr, 0, s);
-    if (C == 192) return ln_out ? launch_wide_bf16_cfg<192, 1, true>(w, y, x, M, ln_out, ld_out, s) : launch_wide_bf16_cfg<192, 1, false>(w, y, x, M, nullptr, 0, s);
-    if (C == 96) return ln_out ? launch_stat_bf16<true>(w, y, x, M, ln_out, ld_out, s) : launch_stat_bf16<false>(w, y, x, M, nullptr, 0, s);
-    ACX_FAIL(ACX_ERR_SHAPE, "fused bf16 MLP: unsupported channel count %d", C);
+    return act_bf16 ? launch_bf16_any<true>(w, C, y, x, M, s, ln_out, ld_out) : launch_bf16_any<false>(w, C, y, x, M, s, ln_out, ld_out);
 }
 
 }  // namespace acx

@@ -28,10 +28,12 @@ __device__ __forceinline__ float half_sum32(float v) {
 constexpr int kStemGroups = 8;                 // 32-lane groups per workgroup; 56 pixels / 8 = 7 pixels per group and row
 constexpr int kStemRowF4 = kMels / 4;          // 56 float4 per input row = one per output pixel
 
+// OBF: the output tensor is bf16 (ACX_PREC_BF16_ACT): a lane's four channels leave as one 8-byte store
+template <bool OBF>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, int T, int H0, long long nrows,
                                                    const float* __restrict__ w /*[96][16]*/,
                                                    const float* __restrict__ bias, const float* __restrict__ lnw,
-                                                   const float* __restrict__ lnb, float* __restrict__ out) {
+                                                   const float* __restrict__ lnb, void* __restrict__ out_) {
     __shared__ float4 patch[2][4][kStemRowF4];          // double-buffered: one barrier per row
     const int tid = threadIdx.x;
     const int l32 = tid & 31;
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
         __syncthreads();                                // this row's patches visible; the other buffer is free again
         const long long row_n = row + gridDim.x;
         if (row_n < nrows) nxt = fetch(row_n);          // in flight under this row's arithmetic
-        float* orow = out + row * (long long)(kStemW * 96) + ch;
+        float* orow = reinterpret_cast<float*>(out_) + row * (long long)(kStemW * 96) + ch;
+        __bf16* orow_b = reinterpret_cast<__bf16*>(out_) + row * (long long)(kStemW * 96) + ch;
 #pragma unroll
         for (int i = 0; i < kStemW / kStemGroups; ++i) {
             const int px = grp + kStemGroups * i;
@@ -94,21 +97,27 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
             for (int c = 0; c < 4; ++c) acc[c] -= mean;
             const float var = half_sum32(((acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3])) * keep) * (1.0f / 96.0f);
             const float rstd = 1.0f / sqrtf(var + 1e-6f);
-            if (owner)
-                *reinterpret_cast<float4*>(orow + px * 96) =
-                    make_float4(fmaf(acc[0] * rstd, gw[0], gb[0]), fmaf(acc[1] * rstd, gw[1], gb[1]),
-                                fmaf(acc[2] * rstd, gw[2], gb[2]), fmaf(acc[3] * rstd, gw[3], gb[3]));
+            if (owner) {
+                const float o0 = fmaf(acc[0] * rstd, gw[0], gb[0]), o1 = fmaf(acc[1] * rstd, gw[1], gb[1]),
+                            o2 = fmaf(acc[2] * rstd, gw[2], gb[2]), o3 = fmaf(acc[3] * rstd, gw[3], gb[3]);
+                if (OBF) *reinterpret_cast<uint2*>(orow_b + px * 96) = uint2{acx_pack_bf16x2(o0, o1), acx_pack_bf16x2(o2, o3)};
+                else *reinterpret_cast<float4*>(orow + px * 96) = make_float4(o0, o1, o2, o3);
+            }
         }
         buf ^= 1;
     }
 }
 
-int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, float* out, hipStream_t s) {
+int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, void* out, hipStream_t s, bool act_bf16) {
     const long long nrows = (long long)B * H0;
     long long blocks = nrows < 2048 ? nrows : 2048;     // 8 resident workgroups per CU, every workgroup walks ~8 rows at B = 64
     ProfScope ps(c, ACX_K_STEM, s);
-    stem_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, T, H0, nrows, c->d_stem_w, c->d_stem_b,
-                                                              c->d_stem_lnw, c->d_stem_lnb, out);
+    if (act_bf16)
+        stem_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, T, H0, nrows, c->d_stem_w, c->d_stem_b,
+                                                                        c->d_stem_lnw, c->d_stem_lnb, out);
+    else
+        stem_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, T, H0, nrows, c->d_stem_w, c->d_stem_b,
+                                                                         c->d_stem_lnw, c->d_stem_lnb, out);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

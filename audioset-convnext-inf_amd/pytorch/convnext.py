@@ -212,7 +212,9 @@ class ConvNeXt(nn.Module):
         accumulate -- fp32-grade (1e-3 parity), 16/3 of the f32-MFMA rate.  "fp32": v_mfma_f32_32x32x2_f32 on the
         fp32 operands themselves.  "bf16": pointwise / downsample contractions with bf16 operands and fp32
         accumulation (NOT within the 1e-3 bar); LayerNorm, residual stream, depthwise conv, frontend and head stay
-        fp32 in every mode.  The reference has no such switch (closest: torch autocast around its nn.Linear layers)."""
+        fp32 in every mode.  "bf16a": "bf16" plus the activations of stages 0-2 (residual stream, depthwise-conv output) stored
+        in HBM as bf16 -- half the activation bytes; statistics, accumulation, GELU and the residual add stay fp32.
+        The reference has no such switch (closest: torch autocast around its nn.Linear layers)."""
         if precision not in _ffi.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_ffi.PRECISIONS))
         self.precision = precision

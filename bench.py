@@ -77,13 +77,17 @@ def algorithmic_work(B, L, precision="fp32"):
         ws.append(ws[-1] // 2)
     pix = [B * h * w for h, w in zip(hs, ws)]
     work = {k: [0.0, 0.0] for k in _ffi.KERNEL_CLASSES}
+    act = precision == "bf16a"                  # activations of stages 0-2 stored as bf16
+    if act:
+        precision = "bf16"
+    asz = lambda s: 2 if (act and s < 3) else 4
     work["frontend"] = [0.0, B * L * 4 + B * T * 224 * 4]
-    work["stem"] = [2.0 * pix[0] * 16 * 96, B * T * 224 * 4 + pix[0] * 96 * 4]
+    work["stem"] = [2.0 * pix[0] * 16 * 96, B * T * 224 * 4 + pix[0] * 96 * asz(0)]
     for s in range(4):
         C = DIMS[s]
         n = DEPTHS[s]
         work["dwconv"][0] += n * 2.0 * 49 * pix[s] * C
-        work["dwconv"][1] += n * 2.0 * pix[s] * C * 4                      # read x, write y
+        work["dwconv"][1] += n * 2.0 * pix[s] * C * asz(s)                 # read x, write y
         if precision == "fp32_split" and (s in SPLIT_FUSED_STAGES or s in SPLIT_WIDE_STAGES):
             k = "mlp_fused" if s in SPLIT_FUSED_STAGES else "mlp_wide"
             work[k][0] += n * 4.0 * pix[s] * C * 4 * C
@@ -96,7 +100,7 @@ def algorithmic_work(B, L, precision="fp32"):
             work["pw2"][1] += n * (pix[s] * 4 * C * 4 + 2.0 * pix[s] * C * 4)
         elif precision == "bf16" and s in BF16_WIDE_STAGES:
             work["mlp_wide"][0] += n * 4.0 * pix[s] * C * 4 * C
-            work["mlp_wide"][1] += n * 3.0 * pix[s] * C * 4                    # y in, x in, x out
+            work["mlp_wide"][1] += n * 3.0 * pix[s] * C * asz(s)               # y in, x in, x out
         elif precision == "bf16":
             Cp = (C + 63) // 64 * 64
             work["rowstats"][1] += n * (pix[s] * C * 4 + pix[s] * Cp * 2)
@@ -116,7 +120,7 @@ def algorithmic_work(B, L, precision="fp32"):
         if s > 0:
             work["downsample"][0] += 2.0 * pix[s] * 4 * DIMS[s - 1] * C
             esz = 2 if precision == "bf16" else 4
-            work["downsample"][1] += pix[s - 1] * DIMS[s - 1] * esz + pix[s] * C * 4
+            work["downsample"][1] += pix[s - 1] * DIMS[s - 1] * esz + pix[s] * C * asz(s)
             if not ((precision == "fp32_split" and ((s - 1) in SPLIT_FUSED_STAGES or (s - 1) in SPLIT_WIDE_STAGES))
                     or (precision == "bf16" and (s - 1) in BF16_WIDE_STAGES)):
                 # (in fp32_split / bf16 the last fused block of the previous stage writes the normalised rows itself)
@@ -249,7 +253,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--mode", default="logits", choices=["logits", "scene", "frame"])
-    ap.add_argument("--precision", default=os.environ.get("ACX_PRECISION", "fp32_split"), choices=["fp32_split", "fp32", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("ACX_PRECISION", "fp32_split"), choices=["fp32_split", "fp32", "bf16", "bf16a"],
                     help="fp32_split (default) and fp32 both meet BASELINE configs[1]'s 1e-3 fp32 parity: split = fp32 "
                          "operands as fp16 hi+lo pairs on the fp16 matrix cores, fp32 = v_mfma_f32_32x32x2_f32; "
                          "bf16 = the arithmetic of configs[2] (bf16 contractions, fp32 LayerNorm / residual / accumulate)")
@@ -294,7 +298,7 @@ def main():
             sys.exit(3)
 
     from audioset_convnext_inf_amd import parallel
-    bf16 = args.precision == "bf16"
+    bf16 = args.precision in ("bf16", "bf16a")          # "bf16a": activations of stages 0-2 in HBM as bf16 too (acx.h)
     split = args.precision == "fp32_split"
     B = args.batch
     if args.dry_run:
@@ -350,7 +354,7 @@ def main():
         "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16" if bf16 else ("f32 (GEMM operands as fp16 hi+lo pairs = 24 significant bits, 3 fp16 MFMAs per "
+        "dtype": ("bf16 (contractions and stored activations of stages 0-2)" if args.precision == "bf16a" else "bf16") if bf16 else ("f32 (GEMM operands as fp16 hi+lo pairs = 24 significant bits, 3 fp16 MFMAs per "
                                       "product, fp32 accumulate; all else fp32)" if split else "f32"),
         "data": "synthetic", "rccl_ranks": joined,
         "config": {"workload": "ConvNeXt-Tiny bs=%d per GPU, synthetic 10 s @ 32 kHz waveforms resident in HBM, "
@@ -393,8 +397,8 @@ def main():
                           "algorithmic_GBs": nbytes / (ms * 1e-3) / 1e9}
         line["kernels"] = kernels
         # the matrix kernels by NAME: the event classes pw1 and pw2 are launches of one kernel
-        gemm_name = {"fp32": "gemm_f32_kernel", "bf16": "gemm_bf16_kernel", "fp32_split": "gemm_split_kernel"}[args.precision]
-        fused_name = {"fp32": "mlp_fused_kernel", "bf16": "mlp_fused_bf16_kernel", "fp32_split": "mlp_fused_split_kernel"}[args.precision]
+        gemm_name = {"fp32": "gemm_f32_kernel", "bf16": "gemm_bf16_kernel", "bf16a": "gemm_bf16_kernel", "fp32_split": "gemm_split_kernel"}[args.precision]
+        fused_name = {"fp32": "mlp_fused_kernel", "bf16": "mlp_fused_bf16_kernel", "bf16a": "mlp_fused_bf16_kernel", "fp32_split": "mlp_fused_split_kernel"}[args.precision]
         groups = {gemm_name + " (pwconv1+GELU and pwconv2+residual launches, two-GEMM stages)": ("pw1", "pw2"),
                   fused_name + " (LN+pwconv1+GELU+pwconv2+residual in one launch)": ("mlp_fused",),
                   ("mlp_fused_wide_bf16_kernel (LN+pwconv1+GELU+pwconv2+residual in one launch, stages 0-2)" if bf16 else

@@ -60,11 +60,18 @@ enum acx_mode {
 enum acx_precision {
     ACX_PREC_F32 = 0,         /* v_mfma_f32_32x32x2_f32: fp32 operands on the matrix cores */
     ACX_PREC_BF16 = 1,        /* bf16 operands, fp32 accumulate (NOT within the 1e-3 bar) */
-    ACX_PREC_F32_SPLIT = 2    /* DEFAULT.  fp32 operands carried as fp16 hi + fp16 lo (24 significant bits), three fp16
+    ACX_PREC_F32_SPLIT = 2,   /* DEFAULT.  fp32 operands carried as fp16 hi + fp16 lo (24 significant bits), three fp16
                                * MFMAs per product, fp32 accumulate: fp32-grade results (same parity tests and
                                * tolerances as ACX_PREC_F32, plus tests/test_gpu_stress.py) at 16/3 of the f32-MFMA
                                * rate.  Its kernels launch CU-exclusive workgroups (whole LDS + whole register file of
                                * a CU): work of other streams or processes never shares a CU with them. */
+    ACX_PREC_BF16_ACT = 3     /* ACX_PREC_BF16 with the ACTIVATIONS of stages 0-2 (residual stream and depthwise-conv
+                               * output: 97 % of the activation bytes) stored in HBM as bf16 as well -- BASELINE configs[2]
+                               * read as SURVEY 8d does (107.5 MB of activation traffic per clip).  LayerNorm statistics,
+                               * accumulation, GELU, the residual add and the depthwise arithmetic stay fp32; a tensor is
+                               * rounded to bf16 (nearest even) when it is written.  Stage 3, frontend and head as in
+                               * ACX_PREC_BF16.  The per-layer entry points keep fp32 tensors at the ABI (acx_block converts
+                               * at its boundary so that the block runs in this arithmetic). */
 };
 
 /* kernel classes for acx_profile_read() */

@@ -1,4 +1,7 @@
-"""bf16 precision mode (`model.set_precision("bf16")`, BASELINE configs[2] "bf16 with fp32 LayerNorm") on the GPU.
+"""bf16 precision modes (BASELINE configs[2] "bf16 with fp32 LayerNorm") on the GPU, every test in both:
+  "bf16"   bf16 MFMA operands, activations in HBM stay fp32;
+  "bf16a"  additionally the activations of stages 0-2 (residual stream, depthwise-conv output) are STORED as bf16 -- SURVEY 8d's
+           reading of configs[2] (107.5 MB of activation traffic per clip); arithmetic between load and store unchanged.
 
 The 1e-3 parity bar belongs to the fp32 path; here the checks are
   (i)  kernel exactness: one block / one downsample layer against an emulation of the same arithmetic built from
@@ -30,13 +33,13 @@ def bf(t):
     return t.to(torch.bfloat16).to(torch.float64)
 
 
-@pytest.fixture(scope="module")
-def model16(synth_sd):
+@pytest.fixture(scope="module", params=["bf16", "bf16a"])
+def model16(synth_sd, request):
     assert torch.cuda.is_available(), "gpu tests need a GPU"
     m = convnext_tiny(pretrained=False, strict=False, drop_path_rate=0.0, after_stem_dim=[252, 56],
                       use_speed_perturb=False)
     m.load_state_dict(synth_sd)
-    return m.to("cuda").eval().set_precision("bf16")
+    return m.to("cuda").eval().set_precision(request.param)
 
 
 @pytest.fixture(scope="module")
@@ -68,14 +71,20 @@ def ln_plain(x, C):
 
 @pytest.mark.parametrize("rows", [None, 3])
 @pytest.mark.parametrize("s", [0, 1, 2, 3])
-def test_block_bf16(ctx16, taps, synth_sd, s, rows):
+def test_block_bf16(ctx16, model16, taps, synth_sd, s, rows):
     from oracle import ref_cpu
     C = DIMS[s]
     p = "stages.%d.0." % s
     x0 = taps["ds%d" % s]                                  # NCHW fp32
     if rows is not None:                                   # 3 x W pixels of one clip: not a multiple of any kernel's row tile
         x0 = x0[:1, :, :rows, :].contiguous()
+    x_in = x0
+    act = model16.precision == "bf16a" and s < 3           # stored tensors of this stage are bf16: x in, y, x out
+    if act:
+        x0 = x0.to(torch.bfloat16).float()                 # what the block reads
     y = ref_cpu.block_dwconv(synth_sd, s, 0, x0).permute(0, 2, 3, 1)
+    if act:
+        y = y.to(torch.bfloat16).float()                   # the depthwise conv's output as stored
     # the arithmetic of the bf16 block kernels (mlp_fused_wide_bf16.hip; stage 3: run_mlp_bf16 in api.hip): folds in
     # fp32/fp64, operands rounded to bf16, wide accumulation
     yn = bf(ln_plain(y, C))
@@ -85,8 +94,10 @@ def test_block_bf16(ctx16, taps, synth_sd, s, rows):
     g = synth_sd[p + "gamma"].double()
     w2 = bf((g[:, None] * synth_sd[p + "pwconv2.weight"].double()).float())
     ref = x0.permute(0, 2, 3, 1).double() + h @ w2.T + g * synth_sd[p + "pwconv2.bias"].double()
+    if act:
+        ref = ref.float().to(torch.bfloat16).double()      # ... and what it writes
 
-    x = nhwc(x0)
+    x = nhwc(x_in)
     B, H, W, _ = x.shape
     need = ctypes.c_size_t()
     _ffi.check(_ffi.lib().acx_block_scratch_bytes(s, B, H, W, ctypes.byref(need)))
@@ -94,7 +105,8 @@ def test_block_bf16(ctx16, taps, synth_sd, s, rows):
     _ffi.check(_ffi.lib().acx_block(ctx16.handle, s, 0, _ffi.ptr(x), B, H, W, _ffi.ptr(scratch), need.value, sp()))
     torch.cuda.synchronize()
     d_emu = maxdiff(x, ref)
-    assert d_emu < EMU_TOL
+    # bf16a: a stored value may round the other way when the fp32 sum sits at a rounding boundary -- one bf16 ulp of the result
+    assert d_emu < (EMU_TOL if not act else max(EMU_TOL, 2.0 ** -7 * float(ref.abs().max())))
     if rows is None:
         d_f32 = maxdiff(x.permute(0, 3, 1, 2), taps["s%d.b0.out" % s])
         print("stage %d: vs bf16 emulation %.3g, vs fp32 tap %.3g" % (s, d_emu, d_f32))
@@ -134,13 +146,39 @@ def test_e2e_bf16_drift_on_demo_clip(model16, golden_dir):
     d_scene = maxdiff(model16.forward_scene_embeddings(wav), torch.from_numpy(g["scene"]))
     print("bf16 e2e drift: logits %.3g probs %.3g scene %.3g" % (d_logit, d_prob, d_scene))
     assert d_logit < DRIFT_E2E_TOL and d_prob < 0.05 and d_scene < DRIFT_E2E_TOL
-    ref_lbl = np.where(g["probs"][0] > 0.25)[0]
-    got_lbl = np.where(out["clipwise_output"][0].cpu().numpy() > 0.25)[0]
-    assert np.array_equal(ref_lbl, got_lbl)
+    ref_dec = g["probs"][0] > 0.25
+    got_dec = out["clipwise_output"][0].cpu().numpy() > 0.25
+    if model16.precision == "bf16":
+        assert np.array_equal(ref_dec, got_dec)
+    else:           # bf16a: a class whose probability sits within the drift of the threshold may flip -- at most 0.5 % of them
+        assert float((ref_dec == got_dec).mean()) >= 0.995, int((ref_dec != got_dec).sum())
     # ranking of the confident classes survives
     top_ref = np.argsort(-g["logits"][0])[:5]
     top_got = np.argsort(-out["clipwise_logits"][0].cpu().numpy())[:5]
     assert set(top_ref[:3]) <= set(top_got)
+
+
+def test_bf16_label_agreement_on_goldens(model16, golden_dir):
+    """Decisions at the demo's 0.25 threshold against the fp32 goldens of the reference class (g2_taps: seeded clips, g2_edge:
+    noise / silence / square / sweep): >= 99.5 % of the (clip, class) decisions agree."""
+    agree = total = 0
+    for name in ("g2_taps.npz", "g2_edge.npz"):
+        g = np.load(os.path.join(golden_dir, name))
+        wkeys = [k for k in g.files if k == "wav" or k.startswith("wav_")]
+        for wk in wkeys:
+            pk = "probs" if wk == "wav" else "probs_" + wk[4:]
+            if pk not in g.files:
+                continue
+            wav = torch.from_numpy(g[wk]).cuda()
+            if wav.dim() == 1:
+                wav = wav[None]
+            got = model16(wav)["clipwise_output"].cpu().numpy() > 0.25
+            ref = g[pk] > 0.25
+            agree += int((got == ref).sum())
+            total += ref.size
+    assert total > 0
+    print("label agreement at 0.25: %d / %d = %.4f" % (agree, total, agree / total))
+    assert agree / total >= 0.995
 
 
 def test_bf16_batch_rows_independent(model16):
@@ -166,15 +204,16 @@ def test_bf16_ragged_clip_lengths(synth_sd):
         m.set_precision("fp32_split")
         ref = m(wav)["clipwise_logits"].clone()
         ref_fr = m.forward_frame_embeddings(wav).clone()
-        m.set_precision("bf16")
-        a = m(wav)["clipwise_logits"].clone()
-        fr = m.forward_frame_embeddings(wav).clone()
-        assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(fr).all())
-        solo = m(wav[B - 1:B])["clipwise_logits"]
-        assert torch.equal(solo[0], a[B - 1])
-        d, dfr = maxdiff(a, ref), maxdiff(fr, ref_fr)
-        print("B=%d L=%d: bf16 vs fp32_split: logits %.3g frame %.3g" % (B, L, d, dfr))
-        assert d < DRIFT_E2E_TOL and dfr < 2 * DRIFT_E2E_TOL
+        for prec in ("bf16", "bf16a"):
+            m.set_precision(prec)
+            a = m(wav)["clipwise_logits"].clone()
+            fr = m.forward_frame_embeddings(wav).clone()
+            assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(fr).all())
+            solo = m(wav[B - 1:B])["clipwise_logits"]
+            assert torch.equal(solo[0], a[B - 1])
+            d, dfr = maxdiff(a, ref), maxdiff(fr, ref_fr)
+            print("B=%d L=%d: %s vs fp32_split: logits %.3g frame %.3g" % (B, L, prec, d, dfr))
+            assert d < DRIFT_E2E_TOL and dfr < 2 * DRIFT_E2E_TOL
 
 
 def test_bf16_forward_is_graph_capturable(model16):
@@ -210,5 +249,7 @@ def test_precision_switch_rebuilds_context(synth_sd):
     c = m.set_precision("fp32")(wav)["clipwise_logits"].clone()
     assert torch.equal(a, c)
     assert not torch.equal(a, b) and maxdiff(a, b) < DRIFT_E2E_TOL
+    d = m.set_precision("bf16a")(wav)["clipwise_logits"].clone()
+    assert not torch.equal(b, d) and maxdiff(a, d) < DRIFT_E2E_TOL
     with pytest.raises(ValueError):
         m.set_precision("fp8")

@@ -77,10 +77,12 @@ def test_bs64_fp32_four_clips_all_outputs_vs_oracle(synth_sd, precision):
     assert max(res.values()) < E2E_TOL, res
 
 
-def test_bf16_bs64_ten_seconds(synth_sd):
-    """configs[2], one rank's shard: 64 x 10 s in bf16 arithmetic -- finite, clip-independent, and within the drift bf16
-    operands allow of the fp32-grade result (same bounds as tests/test_gpu_bf16.py uses at small sizes)."""
-    m16 = make_model(synth_sd, "bf16")
+@pytest.mark.parametrize("mode", ["bf16", "bf16a"])
+def test_bf16_bs64_ten_seconds(synth_sd, mode):
+    """configs[2], one rank's shard: 64 x 10 s in bf16 arithmetic ("bf16a": with the activations of stages 0-2 stored as bf16
+    too) -- finite, clip-independent, and within the drift bf16 operands allow of the fp32-grade result (same bounds as
+    tests/test_gpu_bf16.py uses at small sizes)."""
+    m16 = make_model(synth_sd, mode)
     m32 = make_model(synth_sd, "fp32_split")
     wav = synth.synth_waveforms(64, L10, seed=99).cuda()
     o16 = m16(wav)
@@ -89,7 +91,7 @@ def test_bf16_bs64_ten_seconds(synth_sd):
         assert torch.equal(m16(wav[b:b + 1])["clipwise_logits"][0], o16["clipwise_logits"][b]), b
     o32 = m32(wav)
     d = maxdiff(o16["clipwise_logits"], o32["clipwise_logits"])
-    print("bf16 vs fp32_split at bs=64 x 10 s: logits max abs diff %.3g" % d)
+    print("%s vs fp32_split at bs=64 x 10 s: logits max abs diff %.3g" % (mode, d))
     assert d < 0.25
     agree = (o16["clipwise_output"] > 0.25) == (o32["clipwise_output"] > 0.25)
     assert float(agree.float().mean()) > 0.995
@@ -183,7 +185,7 @@ def test_concurrent_forwards_on_two_streams(synth_sd):
         assert torch.equal(o1, r1) and torch.equal(o2, r2)
 
 
-@pytest.mark.parametrize("precision", ["fp32_split", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32_split", "bf16", "bf16a"])
 def test_forward_beside_foreign_work_on_another_stream(synth_sd, precision):
     """The round-1 defect: while a dense 16-bit-MFMA kernel ran, FFT-type kernels of OTHER streams (rocFFT included)
     returned wrong results.  Every such kernel now launches CU-exclusive workgroups; here a forward of

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): bench line + rocprofv3 kernel stats + PMC passes -> gpurun_out/final/
 set -x
-# usage: collect_profiles.sh [precision]   (fp32_split | fp32 | bf16)
+# usage: collect_profiles.sh [precision]   (fp32_split | fp32 | bf16 | bf16a)
 PREC=${1:-fp32_split}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$PREC; rm -rf $O; mkdir -p $O
 cd $R && python bench.py --precision $PREC --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err

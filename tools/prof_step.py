@@ -15,7 +15,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=1)
 ap.add_argument("--samples", type=int, default=320000)
 ap.add_argument("--mode", default="logits")
-ap.add_argument("--precision", default="fp32_split", choices=["fp32", "fp32_split", "bf16"])
+ap.add_argument("--precision", default="fp32_split", choices=["fp32", "fp32_split", "bf16", "bf16a"])
 a = ap.parse_args()
 os.environ.setdefault("ACX_SPLIT_STREAMS", "0")      # one stream: per-dispatch counters of kernels that do not overlap
 m = convnext_tiny(after_stem_dim=[252, 56])
