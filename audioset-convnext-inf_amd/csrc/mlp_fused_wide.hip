@@ -12,10 +12,12 @@
 //               LDS holds a ring of three segments: one being multiplied, one landed or landing, one being requested.
 //   schedule    segment 2k-1: phase 1 of chunk k    X^T[32 hidden x 32 px] = W1c . LN(y)^T     3 C/16 MFMAs on Xn
 //               segment 2k  : phase 2 of chunk k-1  out^T[C x 32 px] += W2c . G(k-1)            3 C/16 MFMAs
-//               GELU + hi/lo split of X(k) -> G(k): 64 micro-steps of 2-6 vector instructions, the first half dealt over
-//               the MFMAs of segment 2k, the second half over those of segment 2k+1 -- one wave per SIMD issues both
-//               streams, and only ~24 cycles of vector issue hide behind an MFMA (MI355X_MICROARCH.md, cycle constants):
-//               measured, all of the GELU inside the phase-2 segment cost 73 of 219 us per tile (tools/run_wide_lab.sh).
+//               GELU + hi/lo split of X(k) -> G(k): 30 single-instruction "nano-steps" per register pair (split_math.h,
+//               gelu_nano), half of the pairs dealt over the MFMAs of segment 2k, the other half over those of segment
+//               2k+1.  One wave per SIMD issues both streams: about five single-issue instructions ride for free behind
+//               a 32x32x16 MFMA, every further one costs ~5 cycles (profiles/r03_d_coissue_table_full.txt), so each MFMA
+//               gap gets at most four slots, fewer where an LDS-DMA piece or the fragment reads of the next unit already
+//               sit in it (WideCfg::gap_free).
 //               The DMA pieces of segment s+2 are threaded through the units of segment s; one counted s_waitcnt vmcnt +
 //               s_barrier per segment.
 // HBM traffic per block: read y, read x, write x (3 C H W 4 bytes) + the weight stream from L2 / MALL.

@@ -10,5 +10,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/b
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 $R/tools/prof_step.py --precision $PREC > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/tools/prof_step.py --precision $PREC > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/tools/prof_step.py --precision $PREC > $O/pmc_write.log 2>&1
-cd $R && python tools/pmc_table.py $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/pmc_per_kernel.csv $O/traffic.json > $O/pmc_table.log 2>&1
+cd $R && python tools/pmc_table.py $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/pmc_per_kernel.csv $O/traffic.json $PREC > $O/pmc_table.log 2>&1
 tail -3 $O/pmc_table.log; cat $O/bench.json | cut -c1-400

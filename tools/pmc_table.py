@@ -2,7 +2,7 @@
 """Merge three rocprofv3 --pmc passes (SQ+GRBM | FETCH_SIZE | WRITE_SIZE) of tools/prof_step.py into one
 per-kernel table and a per-kernel-class traffic summary (HBM bytes per launch, FETCH_SIZE doubled as
 MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950).
-usage: pmc_table.py <dir_sq> <dir_fetch> <dir_write> <out_csv> <out_json>"""
+usage: pmc_table.py <dir_sq> <dir_fetch> <dir_write> <out_csv> <out_json> [precision label]"""
 import collections, csv, glob, json, sys
 
 def load(d):
@@ -27,10 +27,11 @@ def cls(name):
         return {"1": "pw1", "2": "pw2"}.get(t[4], "downsample")
     return None
 
+PREC = sys.argv[6] if len(sys.argv) > 6 else "fp32_split"
 sq, fe, wr = load(sys.argv[1]), load(sys.argv[2]), load(sys.argv[3])
 agg = collections.OrderedDict()
 with open(sys.argv[4], "w") as out:
-    out.write("# one forward, B=64 x 10 s (tools/prof_step.py, default precision, one stream); three separate rocprofv3 --pmc passes.\n")
+    out.write("# one forward, B=64 x 10 s (tools/prof_step.py --precision %s, one stream); three separate rocprofv3 --pmc passes.\n" % PREC)
     out.write("# fetch_MB_x2 = 2 * FETCH_SIZE (gfx950 reports half the bytes of 16 B/lane streaming reads); write_MB = WRITE_SIZE.\n")
     out.write("class,kernel,grid,dur_us,clock_GHz,waves_per_SIMD,wait_any,wait_inst_any,valu_active,mfma_util,lds_bank_conflict_per_cu_cycle,fetch_MB_x2,write_MB\n")
     for x, y, z in zip(sq, fe, wr):
@@ -51,5 +52,5 @@ summary = {c: {"launches_per_step": a["launches"], "hbm_traffic_bytes_per_launch
                "fetch_bytes_per_launch_x2": a["fetch_MB_x2"] * 1e6 / a["launches"], "write_bytes_per_launch": a["write_MB"] * 1e6 / a["launches"],
                "mfma_util_cycles": a["mfma_busy"] / a["simd_cycles"]} for c, a in agg.items()}
 json.dump({"source": "rocprofv3 --pmc, 3 passes: SQ_*+GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE; FETCH_SIZE x2 (gfx950 correction)",
-           "workload": "one forward, B=64, 10 s @ 32 kHz (tools/prof_step.py, default precision, one stream)", "classes": summary}, open(sys.argv[5], "w"), indent=1)
+           "workload": "one forward, B=64, 10 s @ 32 kHz (tools/prof_step.py --precision %s, one stream)" % PREC, "classes": summary}, open(sys.argv[5], "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -21,6 +21,12 @@ int main(int argc, char** argv) {
 #ifndef WIDE_FN
 #define WIDE_FN launch_mlp_fused_wide
 #endif
+#ifdef WIDE_BF16   /* mlp_fused_wide_bf16.hip: WIDE_BF16 = 0 (fp32 activations in HBM) or 1 (bf16 activations) */
+#define WIDE_CALL() acx::launch_mlp_fused_wide_bf16(nullptr, bw, C, y, x, M, 0, nullptr, 0, WIDE_BF16 != 0)
+#else
+#define WIDE_BF16 0
+#define WIDE_CALL() acx::WIDE_FN(nullptr, bw, C, y, x, M, 0)
+#endif
     const int C = WIDE_C;
     const long long M = argc > 1 ? atoll(argv[1]) : 64LL * 252 * 56 * 96 / C;
     float *y, *x, *b1, *b2; char* w;
@@ -29,10 +35,14 @@ int main(int argc, char** argv) {
     {
         std::vector<float> h((size_t)M * C);
         for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((int)((i * 2654435761u) >> 20 & 0xfff) - 2048) * 1e-3f;
-        hipMemcpy(y, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-        hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
         hipMemcpy(b1, h.data(), 4 * C * 4, hipMemcpyHostToDevice);
         hipMemcpy(b2, h.data(), C * 4, hipMemcpyHostToDevice);
+        if (WIDE_BF16) {      // the same values as bf16 (upper halves of the floats), packed
+            uint16_t* hb = reinterpret_cast<uint16_t*>(h.data());
+            for (size_t i = 0; i < h.size(); ++i) { uint32_t u; std::memcpy(&u, &h[i], 4); hb[i] = (uint16_t)(u >> 16); }
+        }
+        hipMemcpy(y, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
         std::vector<uint16_t> hw(wbytes / 2);
         for (size_t i = 0; i < hw.size(); ++i) {
             const unsigned r = (unsigned)((i * 2654435761u) >> 9);
@@ -43,14 +53,14 @@ int main(int argc, char** argv) {
         hipMemcpy(w, hw.data(), wbytes, hipMemcpyHostToDevice);
     }
     acx::BlockW bw;
-    bw.wstream_s = reinterpret_cast<uint16_t*>(w); bw.wpack_s = reinterpret_cast<uint16_t*>(w); /* (mlp_fused_split.hip reads wpack_s) */ bw.b1 = b1; bw.b2 = b2; bw.w1s_scale = 1.f; bw.w2s_scale = 1.f; bw.hid_scale = 16.f;
+    bw.wstream_s = reinterpret_cast<uint16_t*>(w); bw.wstream_b = reinterpret_cast<uint16_t*>(w); bw.wpack_s = reinterpret_cast<uint16_t*>(w); /* (mlp_fused_split.hip reads wpack_s) */ bw.b1 = b1; bw.b2 = b2; bw.w1s_scale = 1.f; bw.w2s_scale = 1.f; bw.hid_scale = 16.f;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) if (acx::WIDE_FN(nullptr, bw, C, y, x, M, 0) != 0) return 1;
+    for (int i = 0; i < 5; ++i) if (WIDE_CALL() != 0) return 1;
     hipDeviceSynchronize();
     float best = 1e9f;
     for (int rep = 0; rep < 6; ++rep) {
         hipEventRecord(e0, 0);
-        for (int r = 0; r < 10; ++r) acx::WIDE_FN(nullptr, bw, C, y, x, M, 0);
+        for (int r = 0; r < 10; ++r) WIDE_CALL();
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms / 10 < best) best = ms / 10;
