@@ -32,6 +32,7 @@ SIGNATURES = {
     "acx_num_frames": (_c_int, [_c_i64, _pint]),
     "acx_stage_hw": (_c_int, [_c_i64, _c_int, _pint, _pint]),
     "acx_workspace_bytes": (_c_int, [_vp, _c_int, _c_i64, _c_int, ctypes.POINTER(_c_sz)]),
+    "acx_sub_batches": (_c_int, [_vp, _c_int, ctypes.POINTER(_c_int)]),
     "acx_forward": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _vp, _vp, _vp, _c_sz, _vp]),
     "acx_logmel_bn0": (_c_int, [_vp, _vp, _c_int, _c_i64, _vp, _c_int, _vp]),
     "acx_stem_ln": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp]),
@@ -138,6 +139,12 @@ class Context:
     def workspace_bytes(self, B, L, mode):
         out = _c_sz()
         check(lib().acx_workspace_bytes(self._h, int(B), int(L), int(mode), ctypes.byref(out)))
+        return out.value
+
+    def sub_batches(self, B):
+        """How many sub-batches (on separate streams) a forward of B clips runs as (acx_sub_batches)."""
+        out = _c_int()
+        check(lib().acx_sub_batches(self._h, int(B), ctypes.byref(out)))
         return out.value
 
     def profile(self, on):

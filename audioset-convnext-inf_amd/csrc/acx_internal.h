@@ -154,9 +154,11 @@ struct acx_ctx {
     // two-way batch split over two HIP streams (fork/join by events): kernels of the two halves co-run, so
     // an HBM-bound kernel of one half fills the matrix-pipe-bound phases of the other and vice versa
     bool split_streams = true;    // ACX_SPLIT_STREAMS=0 turns it off
-    bool split_two_streams = false;   // fp32_split arithmetic: two-stream batch split only with ACX_SPLIT_TWO_STREAMS=1
-    // fork/join resources per CALLER stream: forwards issued on different streams (or threads) never share an event
-    struct Aux { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    int split_ways = 0;           // ACX_SPLIT_WAYS=n forces n sub-batches (1 .. kMaxSplitWays); 0: the per-arithmetic default
+    // fork/join resources per CALLER stream: forwards issued on different streams (or threads) never share an event.
+    // Sub-batch 0 runs on the caller's stream, sub-batch i > 0 on streams[i - 1].
+    static constexpr int kMaxSplitWays = 4;
+    struct Aux { hipStream_t streams[kMaxSplitWays - 1] = {}; hipEvent_t fork = nullptr, joins[kMaxSplitWays - 1] = {}; };
     std::map<hipStream_t, Aux> aux;
     std::mutex aux_mutex;
     // identity affine for acx_logmel_bn0(apply_bn0 = 0) (tests): per context, i.e. per device

@@ -598,28 +598,28 @@ static int check_stage(int stage, int block) {
 
 using namespace acx;
 
-// side stream + fork/join events of the two-stream batch split, one set per caller stream.  The set of the null stream is
+// side streams + fork/join events of the batch split (acx_forward), one set per caller stream.  The set of the null stream is
 // created in acx_create; any other stream gets its set at its first split forward -- which must not be a stream capture
 // (hipStreamCreate inside a capture region): warm up once on the stream before capturing, as the host wrapper does.
 // A partial failure destroys what it created; the map is bounded (sets of the least recently added streams are dropped).
-static int make_aux(acx_ctx::Aux* a) {
-    *a = acx_ctx::Aux{};
-    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&a->fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&a->join, hipEventDisableTiming);
-    if (e != hipSuccess) {
-        if (a->join) (void)hipEventDestroy(a->join);
-        if (a->fork) (void)hipEventDestroy(a->fork);
-        if (a->stream) (void)hipStreamDestroy(a->stream);
-        *a = acx_ctx::Aux{};
-        ACX_FAIL(ACX_ERR_HIP, "side stream / events of the two-stream split: %s", hipGetErrorString(e));
-    }
-    return ACX_OK;
-}
 static void destroy_aux(acx_ctx::Aux& a) {
     if (a.fork) (void)hipEventDestroy(a.fork);
-    if (a.join) (void)hipEventDestroy(a.join);
-    if (a.stream) (void)hipStreamDestroy(a.stream);
+    for (auto& j : a.joins) if (j) (void)hipEventDestroy(j);
+    for (auto& s : a.streams) if (s) (void)hipStreamDestroy(s);
+    a = acx_ctx::Aux{};
+}
+static int make_aux(acx_ctx::Aux* a) {
+    *a = acx_ctx::Aux{};
+    hipError_t e = hipEventCreateWithFlags(&a->fork, hipEventDisableTiming);
+    for (int i = 0; i < acx_ctx::kMaxSplitWays - 1 && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&a->streams[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&a->joins[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        destroy_aux(*a);
+        ACX_FAIL(ACX_ERR_HIP, "side streams / events of the batch split: %s", hipGetErrorString(e));
+    }
+    return ACX_OK;
 }
 extern "C" {
 
@@ -642,8 +642,8 @@ int acx_create(int hip_device, acx_ctx** out) {
     {
         const char* e = std::getenv("ACX_SPLIT_STREAMS");
         c->split_streams = !(e && e[0] == '0');
-        const char* e2 = std::getenv("ACX_SPLIT_TWO_STREAMS");
-        c->split_two_streams = e2 && e2[0] == '1';
+        const char* e2 = std::getenv("ACX_SPLIT_WAYS");
+        if (e2 && e2[0] >= '1' && e2[0] <= '0' + acx_ctx::kMaxSplitWays && e2[1] == 0) c->split_ways = e2[0] - '0';
     }
     {   // the null stream's side stream + events exist from the start (nothing is created inside a capture)
         acx_ctx::Aux a;
@@ -712,21 +712,46 @@ int acx_stage_hw(int64_t L, int stage, int* H, int* Wd) {
     return ACX_OK;
 }
 
-// Batches of at least this many clips are split in two halves that run on two streams.
-static constexpr int kSplitMinBatch = 16;
+// A batch is split into sub-batches that run side by side on separate streams when every sub-batch keeps at least this
+// many clips.
+static constexpr int kSplitMinClips = 8;
+
+// number of sub-batches a forward of B clips runs as
+static int split_ways_for(const acx_ctx* c, int B) {
+    int ways = 1;
+    if (c && c->split_streams && !c->prof.on) {
+        // defaults measured at B = 64 (profiles/r03_j_batch_split.txt): sub-batches on separate streams fill each other's
+        // tail rounds and kernel boundaries -- also between CU-exclusive kernels, whose workgroups never share a CU but do
+        // share the chip
+        ways = c->split_ways > 0 ? c->split_ways : 2;
+    }
+    while (ways > 1 && B < ways * kSplitMinClips) --ways;
+    return ways;
+}
+// clips of sub-batch i of `ways`
+static int split_part(int B, int ways, int i) { return B / ways + (i < B % ways ? 1 : 0); }
 
 int acx_workspace_bytes(const acx_ctx* c, int B, int64_t L, int mode, size_t* out_bytes) {
-    (void)c;
     if (!out_bytes || mode < 0 || mode > 2) ACX_FAIL(ACX_ERR_ARG, "acx_workspace_bytes: bad argument");
     Plan p;
     ACX_TRY(make_plan(B, L, &p));
     *out_bytes = p.total;
-    if (B >= kSplitMinBatch) {          // room for the two half-batch plans (whichever way the forward runs)
-        Plan p0, p1;
-        ACX_TRY(make_plan((B + 1) / 2, L, &p0));
-        ACX_TRY(make_plan(B / 2, L, &p1));
-        if (p0.total + p1.total > *out_bytes) *out_bytes = p0.total + p1.total;
+    // room for every way the forward may run (the split can be switched by precision, profiling or the environment)
+    for (int ways = 2; ways <= acx_ctx::kMaxSplitWays && B >= ways * kSplitMinClips; ++ways) {
+        size_t tot = 0;
+        for (int i = 0; i < ways; ++i) {
+            Plan pi;
+            ACX_TRY(make_plan(split_part(B, ways, i), L, &pi));
+            tot += pi.total;
+        }
+        if (tot > *out_bytes) *out_bytes = tot;
     }
+    return ACX_OK;
+}
+
+int acx_sub_batches(const acx_ctx* c, int B, int* out) {
+    if (!c || !out || B <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_sub_batches: bad argument");
+    *out = split_ways_for(c, B);
     return ACX_OK;
 }
 
@@ -737,13 +762,16 @@ static int get_aux(acx_ctx* c, hipStream_t st, acx_ctx::Aux* out) {
     if (it == c->aux.end()) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-            ACX_FAIL(ACX_ERR_STATE, "first two-stream forward on this stream happens inside a stream capture: run one forward on "
+            ACX_FAIL(ACX_ERR_STATE, "first split forward on this stream happens inside a stream capture: run one forward on "
                                     "the stream before capturing (the side stream and its events are created then)");
         acx_ctx::Aux a;
         ACX_TRY(make_aux(&a));
         if (c->aux.size() >= kMaxAuxStreams) {          // drop a set that is not the null stream's
             for (auto d = c->aux.begin(); d != c->aux.end(); ++d)
-                if (d->first != nullptr) { (void)hipStreamSynchronize(d->second.stream); destroy_aux(d->second); c->aux.erase(d); break; }
+                if (d->first != nullptr) {
+                    for (auto sd : d->second.streams) if (sd) (void)hipStreamSynchronize(sd);
+                    destroy_aux(d->second); c->aux.erase(d); break;
+                }
         }
         it = c->aux.emplace(st, a).first;
     }
@@ -794,27 +822,35 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
     if (((uintptr_t)workspace & 255) != 0) ACX_FAIL(ACX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
-    // Clips are independent: a large batch runs as two halves on two streams (fork/join with events, so the call
-    // still looks like one unit of work on `stream` and stays graph-capturable).  Per-kernel event profiling
-    // runs un-split to keep launch durations clean.
-    // The 16-bit-MFMA arithmetics (fp32_split, bf16) run CU-exclusive kernels: nothing co-runs with them on a CU, so the
-    // split buys them nothing (measured +0.7 %) and they keep to one stream unless ACX_SPLIT_TWO_STREAMS=1 asks for it.
-    if (c->split_streams && (c->precision == ACX_PREC_F32 || c->split_two_streams) && !c->prof.on && B >= kSplitMinBatch) {
-        const int B0 = (B + 1) / 2, B1 = B / 2;
-        Plan p0, p1;
-        ACX_TRY(make_plan(B0, L, &p0));
-        ACX_TRY(make_plan(B1, L, &p1));
-        const size_t per_clip0 = mode == ACX_MODE_FRAME ? (size_t)kDims[3] * p0.Hs[3] * p0.Ws[3]
-                                                        : (mode == ACX_MODE_SCENE ? (size_t)kDims[3] : (size_t)kClasses);
+    // Clips are independent: a large batch runs as sub-batches on separate streams (fork/join with events, so the call
+    // still looks like one unit of work on `stream` and stays graph-capturable).  Per-kernel event profiling runs
+    // un-split to keep launch durations clean.  The kernels of the 16-bit arithmetics are CU-exclusive -- nothing
+    // shares a CU with them -- but a second stream's workgroups take the CUs their tail rounds and launch boundaries
+    // leave idle: +4 % (fp32_split) / +11 % (bf16a) at B = 64.
+    const int ways = split_ways_for(c, B);
+    if (ways > 1) {
         acx_ctx::Aux aux;
         ACX_TRY(get_aux(c, st, &aux));
         ACX_HIP(hipEventRecord(aux.fork, st));
-        ACX_HIP(hipStreamWaitEvent(aux.stream, aux.fork, 0));
-        ACX_TRY(forward_one(c, wav, B0, L, mode, out0, out1, ws, p0, st));
-        ACX_TRY(forward_one(c, wav + (size_t)B0 * L, B1, L, mode, out0 + B0 * per_clip0, out1 ? out1 + B0 * per_clip0 : nullptr,
-                            ws + p0.total, p1, aux.stream));
-        ACX_HIP(hipEventRecord(aux.join, aux.stream));
-        ACX_HIP(hipStreamWaitEvent(st, aux.join, 0));
+        size_t ws_off = 0;
+        int b_off = 0;
+        for (int i = 0; i < ways; ++i) {
+            const int Bi = split_part(B, ways, i);
+            Plan pi;
+            ACX_TRY(make_plan(Bi, L, &pi));
+            const size_t per_clip = mode == ACX_MODE_FRAME ? (size_t)kDims[3] * pi.Hs[3] * pi.Ws[3]
+                                                           : (mode == ACX_MODE_SCENE ? (size_t)kDims[3] : (size_t)kClasses);
+            hipStream_t si = i == 0 ? st : aux.streams[i - 1];
+            if (i > 0) ACX_HIP(hipStreamWaitEvent(si, aux.fork, 0));
+            ACX_TRY(forward_one(c, wav + (size_t)b_off * L, Bi, L, mode, out0 + b_off * per_clip,
+                                out1 ? out1 + b_off * per_clip : nullptr, ws + ws_off, pi, si));
+            if (i > 0) {
+                ACX_HIP(hipEventRecord(aux.joins[i - 1], si));
+                ACX_HIP(hipStreamWaitEvent(st, aux.joins[i - 1], 0));
+            }
+            ws_off += pi.total;
+            b_off += Bi;
+        }
         return ACX_OK;
     }
     Plan p;

@@ -349,6 +349,7 @@ def main():
             print("bench.py: gathered %d rows, expected %d" % (out.shape[0], world * B), file=sys.stderr)
             sys.exit(4)
 
+    sub_batches = 1 if args.dry_run else model.native_context(dev).sub_batches(B)
     line = {
         "metric": "clips/sec (10 s @ 32 kHz, ConvNeXt-Tiny, bs=64)", "value": world * B * args.steps / elapsed,
         "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -364,9 +365,15 @@ def main():
                                                         "tests as the native f32-MFMA path)" if split else
                                                         "fp32, native f32 MFMA (BASELINE configs[1])")),
                    "global_batch": world * B, "clip_samples": CLIP_SAMPLES, "weights": "seeded synthetic (synth.py)",
+                   "sub_batches": sub_batches,
                    "parallelism": "clips sharded %d-way, full weight replica per GPU, RCCL all-gather of logits"
                                   % world if world > 1 else "single GPU"},
     }
+    if sub_batches > 1:
+        line["sub_batches_note"] = ("the library runs a batch of %d clips as %d sub-batches side by side on separate streams "
+                                    "(acx_forward, ACX_SPLIT_WAYS); the per-kernel figures under `kernels` / `roofline*` come from "
+                                    "a separate un-split profiled pass (launch durations that do not overlap), so their "
+                                    "sum exceeds ms_per_step by what the overlap saves" % (B, sub_batches))
     if args.dry_run:
         line.update({"dry_run": True, "value": None, "ms_per_step": None,
                      "note": "plumbing check on CPU/gloo with a stand-in model: nothing was measured"})

@@ -122,6 +122,12 @@ ACX_API int acx_stage_hw(int64_t L, int stage, int* H, int* W);
 
 ACX_API int acx_workspace_bytes(const acx_ctx* ctx, int B, int64_t L, int mode, size_t* out_bytes);
 
+/* How acx_forward runs a batch of B clips: as *out sub-batches side by side on separate streams (clips are independent in
+ * eval mode, convnext.py:219,305 -- BatchNorm uses running statistics; every clip's result is bit-identical however the
+ * batch is composed or split).  1 for small batches, while per-kernel profiling is enabled, or with ACX_SPLIT_STREAMS=0;
+ * ACX_SPLIT_WAYS=n (1..4) overrides the default of 2.  No reference counterpart: torch runs one batch on one stream. */
+ACX_API int acx_sub_batches(const acx_ctx* ctx, int B, int* out);
+
 /* The hot path.  wav: device (B, L) fp32.
  *   ACX_MODE_LOGITS: out0 = logits (B,527), out1 = probs (B,527)   [dict keys
  *                    "clipwise_logits" / "clipwise_output", convnext.py:329]

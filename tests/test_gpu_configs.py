@@ -169,7 +169,7 @@ def test_refresh_after_a_data_edit(synth_sd):
 def test_concurrent_forwards_on_two_streams(synth_sd):
     """Two forwards of the same module in flight on two torch streams (the reference module is re-entrant in eval):
     separate workspaces and fork/join events per stream, results equal the serial ones."""
-    m = make_model(synth_sd, "fp32")            # fp32 arithmetic also takes the two-stream batch split inside acx_forward
+    m = make_model(synth_sd, "fp32")            # batches of >= 16 clips also take the sub-batch split inside acx_forward
     w1 = synth.synth_waveforms(17, 32000, seed=41).cuda()
     w2 = synth.synth_waveforms(18, 32000, seed=42).cuda()
     r1 = m(w1)["clipwise_logits"].clone()
@@ -183,6 +183,27 @@ def test_concurrent_forwards_on_two_streams(synth_sd):
             o2 = m(w2)["clipwise_logits"]
         torch.cuda.synchronize()
         assert torch.equal(o1, r1) and torch.equal(o2, r2)
+
+
+@pytest.mark.parametrize("precision", ["fp32_split", "bf16a"])
+def test_sub_batch_split_is_invisible(synth_sd, precision, monkeypatch):
+    """acx_forward runs a batch as sub-batches on side streams (acx_sub_batches; default 2 from 16 clips up): whatever the
+    number of sub-batches -- also an uneven 3-way split of 37 clips -- every clip's result is the one-stream result bit for bit."""
+    wav = synth.synth_waveforms(37, 48000, seed=123).cuda()
+    outs = {}
+    for ways in ("1", "2", "3", "4"):
+        monkeypatch.setenv("ACX_SPLIT_WAYS", ways)        # read at acx_create: a fresh module = a fresh context
+        m = make_model(synth_sd, precision)
+        ctx = m.native_context(wav.device)
+        assert ctx.sub_batches(37) == int(ways) and ctx.sub_batches(15) == 1 and ctx.sub_batches(16) == min(int(ways), 2)
+        outs[ways] = (m(wav)["clipwise_logits"].clone(), m.forward_frame_embeddings(wav).clone())
+        torch.cuda.synchronize()
+        del m
+    for ways in ("2", "3", "4"):
+        assert torch.equal(outs[ways][0], outs["1"][0]) and torch.equal(outs[ways][1], outs["1"][1]), ways
+    monkeypatch.delenv("ACX_SPLIT_WAYS")
+    m = make_model(synth_sd, precision)
+    assert m.native_context(wav.device).sub_batches(64) == 2
 
 
 @pytest.mark.parametrize("precision", ["fp32_split", "bf16", "bf16a"])
