@@ -69,6 +69,15 @@ constexpr size_t kCuLdsBytes = 160 * 1024;
 #define ACX_CLAIM_VGPR(n) asm volatile("" ::: "v" #n)
 #define ACX_CLAIM_AGPR(n) asm volatile("" ::: "a" #n)
 
+// Lanes l and l + 32 -- the two channel halves of one pixel row in the 32 x 32 MFMA layouts -- trade one register each
+// (v_permlane32_swap_b32): afterwards the LOWER lane holds (its own a, the upper lane's a) in (a, b) and the UPPER lane
+// (the lower lane's b, its own b).  Epilogues use it to turn two 8-byte pieces per lane, interleaved with the partner's,
+// into one 16-byte piece per lane: 32 contiguous bytes per row and store instruction instead of 16.
+__device__ __forceinline__ void acx_pair_swap(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+
 // ---- bf16 activations in HBM (ACX_PREC_BF16_ACT, stages 0-2): packed pairs, round to nearest even (v_cvt_pk_bf16_f32) ---
 typedef __bf16 acx_bf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned acx_pack_bf16x2(float lo, float hi) {

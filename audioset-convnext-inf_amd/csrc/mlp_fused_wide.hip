@@ -436,27 +436,28 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             for (int r = 0; r < 16; ++r) { const float u = acc[pt][t][r] - mean; d = fmaf(u, u, d); }
         d += __shfl_xor(d, 32);
         const float sc = kSplitLnScale / sqrtf(d * (1.0f / C) + 1e-6f);
-        if (valid[pt]) {
-            char* op = ln_out + mrow[pt] * (long long)(C * 4) + 8 * hh;
+        // lanes (px, 0) and (px, 1) trade halves so that each writes ONE 16-byte piece per block -- the lower lane the 8 hi
+        // halves, the upper lane the 8 lo halves: 32 contiguous bytes per row and store instruction (the rows are cold: 8-byte
+        // pieces cost a read-for-ownership of every sector)
+        char* op = ln_out + mrow[pt] * (long long)(C * 4) + 16 * hh;
 #pragma unroll
-            for (int t = 0; t < C / 32; ++t) {
+        for (int t = 0; t < C / 32; ++t) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    unsigned uhi[2], ulo[2];
+            for (int q = 0; q < 4; ++q) {
+                unsigned uhi[2], ulo[2];
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        f32x2 v;
-                        v.x = (acc[pt][t][4 * q + 2 * e] - mean) * sc; v.y = (acc[pt][t][4 * q + 2 * e + 1] - mean) * sc;
-                        const h2 h = __builtin_convertvector(v, h2);
-                        const f32x2 back = __builtin_convertvector(h, f32x2);
-                        const h2 l = __builtin_convertvector(v - back, h2);
-                        uhi[e] = __builtin_bit_cast(unsigned, h);
-                        ulo[e] = __builtin_bit_cast(unsigned, l);
-                    }
-                    char* blk = op + (4 * t + q) * 32;          // channels 32t + 8q .. +7: this lane the half 4hh .. +3
-                    *reinterpret_cast<uint2*>(blk) = uint2{uhi[0], uhi[1]};
-                    *reinterpret_cast<uint2*>(blk + 16) = uint2{ulo[0], ulo[1]};
+                for (int e = 0; e < 2; ++e) {
+                    f32x2 v;
+                    v.x = (acc[pt][t][4 * q + 2 * e] - mean) * sc; v.y = (acc[pt][t][4 * q + 2 * e + 1] - mean) * sc;
+                    const h2 h = __builtin_convertvector(v, h2);
+                    const f32x2 back = __builtin_convertvector(h, f32x2);
+                    const h2 l = __builtin_convertvector(v - back, h2);
+                    uhi[e] = __builtin_bit_cast(unsigned, h);
+                    ulo[e] = __builtin_bit_cast(unsigned, l);
+                    acx_pair_swap(uhi[e], ulo[e]);
                 }
+                // block of channels 32t + 8q .. +7: [8 hi][8 lo]
+                if (valid[pt]) *reinterpret_cast<uint4*>(op + (4 * t + q) * 32) = uint4{uhi[0], uhi[1], ulo[0], ulo[1]};
             }
         }
     } else if (valid[pt]) {

@@ -281,19 +281,28 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     phase1(std::true_type{}, n - 1, 2 * n - 3, grp);
     grp = grp == 2 ? 0 : grp + 1;
     // the activations are dead from here on: their registers take the residual x of the tile
-    float4 xr[PT][C / 8];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-#pragma unroll
-        for (int t = 0; t < Cfg::kTiles; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xr[pt][4 * t + q] = acx_ld4<ABF>(x, mrow[pt] * C + 4 * hh + 32 * t + 8 * q);
+    // (not for LNOUT at C = 384: its epilogue needs every accumulator AND every residual value at once for the LayerNorm
+    // statistics -- 288 + working registers: hipcc spilled 640 B per lane around the last segments; the residual of that
+    // variant is read in the epilogue instead, tile by tile, from rows the previous block left in the cache)
+    constexpr bool kPrefetchX = !(LNOUT && C >= 384);
+    float4 xr[PT][kPrefetchX ? C / 8 : 1];
+    // C = 384: requested one segment later, once the pre-activation tiles of the last GELU are dead (two segments ahead
+    // hipcc spilled 156 B per lane around here)
+    constexpr bool kLateX = C >= 384;
+#define ACX_LOAD_XR()                                                                                           \
+    if constexpr (kPrefetchX) {                                                                                 \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)                                                       \
+        _Pragma("unroll") for (int t = 0; t < Cfg::kTiles; ++t)                                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) xr[pt][4 * t + q] = acx_ld4<ABF>(x, mrow[pt] * C + 4 * hh + 32 * t + 8 * q); \
     }
+    if constexpr (!kLateX) { ACX_LOAD_XR() }
     phase2(std::true_type{}, 2 * n - 2, grp);
     grp = grp == 2 ? 0 : grp + 1;
     ACX_MICRO_RANGE(1, 0, Cfg::kHalf)       // second half of the last chunk's GELU: no phase-1 segment left to ride on
     ACX_PACK_G()
+    if constexpr (kLateX) { ACX_LOAD_XR() }
     phase2(std::false_type{}, 2 * n - 1, grp);
+#undef ACX_LOAD_XR
 #undef ACX_WDMA
 #undef ACX_B8
 #undef ACX_FENCE
@@ -320,7 +329,9 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 bb = *reinterpret_cast<const float4*>(b2 + 32 * t + 8 * q + 4 * hh);
-                    const float4 v = xr[pt][4 * t + q];
+                    float4 v;
+                    if constexpr (kPrefetchX) v = xr[pt][4 * t + q];
+                    else v = acx_ld4<ABF>(x, mrow[pt] * C + 4 * hh + 32 * t + 8 * q);
                     acc[pt][t][4 * q + 0] += v.x + bb.x; acc[pt][t][4 * q + 1] += v.y + bb.y;
                     acc[pt][t][4 * q + 2] += v.z + bb.z; acc[pt][t][4 * q + 3] += v.w + bb.w;
                     sum += (acc[pt][t][4 * q + 0] + acc[pt][t][4 * q + 1]) + (acc[pt][t][4 * q + 2] + acc[pt][t][4 * q + 3]);
@@ -334,35 +345,57 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
                 for (int r = 0; r < 16; ++r) { const float u = acc[pt][t][r] - mean; d = fmaf(u, u, d); }
             d += __shfl_xor(d, 32);
             const float rstd = 1.0f / sqrtf(d * (1.0f / C) + 1e-6f);
-            if (valid[pt]) {
-                __bf16* op = ln_out + mrow[pt] * (long long)ld_out + 4 * hh;
+            {
+                // lanes (px, 0) and (px, 1) trade pieces so that each writes 16 bytes (8 channels) per store: the lower lane the
+                // group q = 2j, the upper lane the group q = 2j + 1 -- 32 contiguous bytes per row and store instruction (the
+                // rows are cold: 8-byte pieces cost a read-for-ownership of every sector)
+                __bf16* op = ln_out + mrow[pt] * (long long)ld_out + 8 * hh;
 #pragma unroll
                 for (int t = 0; t < Cfg::kTiles; ++t)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint2 o;
-                        o.x = pack_bf16((acc[pt][t][4 * q + 0] - mean) * rstd, (acc[pt][t][4 * q + 1] - mean) * rstd);
-                        o.y = pack_bf16((acc[pt][t][4 * q + 2] - mean) * rstd, (acc[pt][t][4 * q + 3] - mean) * rstd);
-                        *reinterpret_cast<uint2*>(op + 32 * t + 8 * q) = o;
+                    for (int j = 0; j < 2; ++j) {
+                        unsigned e[2], o[2];        // this lane's 4 channels of group 2j / 2j + 1
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            e[w] = pack_bf16((acc[pt][t][8 * j + 2 * w] - mean) * rstd, (acc[pt][t][8 * j + 2 * w + 1] - mean) * rstd);
+                            o[w] = pack_bf16((acc[pt][t][8 * j + 4 + 2 * w] - mean) * rstd, (acc[pt][t][8 * j + 4 + 2 * w + 1] - mean) * rstd);
+                            acx_pair_swap(e[w], o[w]);
+                        }
+                        if (valid[pt]) *reinterpret_cast<uint4*>(op + 32 * t + 16 * j) = uint4{e[0], e[1], o[0], o[1]};
                     }
                 // the row is ld_out = pad64(C) elements long (the GEMM's K is padded with zero weights): zero the padding, or
                 // stale bytes that happen to be NaN would poison the products
-                for (int c = C + 4 * hh; c < ld_out; c += 8)
-                    *reinterpret_cast<uint2*>(ln_out + mrow[pt] * (long long)ld_out + c) = uint2{0u, 0u};
+                if (valid[pt])
+                    for (int c = C + 8 * hh; c < ld_out; c += 16)
+                        *reinterpret_cast<uint4*>(ln_out + mrow[pt] * (long long)ld_out + c) = uint4{0u, 0u, 0u, 0u};
             }
-        } else if (valid[pt]) {
+        } else {
 #pragma unroll
             for (int t = 0; t < Cfg::kTiles; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = 32 * t + 8 * q;
-                    const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
-                    float4 v = xr[pt][4 * t + q];
-                    v.x += acc[pt][t][4 * q + 0] + bb.x;
-                    v.y += acc[pt][t][4 * q + 1] + bb.y;
-                    v.z += acc[pt][t][4 * q + 2] + bb.z;
-                    v.w += acc[pt][t][4 * q + 3] + bb.w;
-                    acx_st4<ABF>(x, mrow[pt] * C + 4 * hh + c, v);
+                for (int j = 0; j < 2; ++j) {
+                    float4 v[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int q = 2 * j + i;
+                        const float4 bb = *reinterpret_cast<const float4*>(b2 + 32 * t + 8 * q + 4 * hh);
+                        v[i] = xr[pt][4 * t + q];
+                        v[i].x += acc[pt][t][4 * q + 0] + bb.x;
+                        v[i].y += acc[pt][t][4 * q + 1] + bb.y;
+                        v[i].z += acc[pt][t][4 * q + 2] + bb.z;
+                        v[i].w += acc[pt][t][4 * q + 3] + bb.w;
+                    }
+                    if constexpr (ABF) {        // bf16 rows: 16-byte pieces by trading halves with the partner lane (as in LNOUT)
+                        unsigned e[2] = {acx_pack_bf16x2(v[0].x, v[0].y), acx_pack_bf16x2(v[0].z, v[0].w)};
+                        unsigned o[2] = {acx_pack_bf16x2(v[1].x, v[1].y), acx_pack_bf16x2(v[1].z, v[1].w)};
+                        acx_pair_swap(e[0], o[0]);
+                        acx_pair_swap(e[1], o[1]);
+                        if (valid[pt])
+                            *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(x) + mrow[pt] * C + 8 * hh + 32 * t + 16 * j) = uint4{e[0], e[1], o[0], o[1]};
+                    } else if (valid[pt]) {
+                        acx_st4<false>(x, mrow[pt] * C + 4 * hh + 32 * t + 16 * j, v[0]);
+                        acx_st4<false>(x, mrow[pt] * C + 4 * hh + 32 * t + 16 * j + 8, v[1]);
+                    }
                 }
         }
     }
@@ -566,33 +599,53 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
                 for (int r = 0; r < 16; ++r) { const float u = acc[t][r] - mean; d = fmaf(u, u, d); }
             d += __shfl_xor(d, 32);
             const float rstd = 1.0f / sqrtf(d * (1.0f / C) + 1e-6f);
-            if (valid) {
-                __bf16* op = ln_out + mrow * (long long)ld_out + 4 * hh;
+            {
+                // 16-byte pieces by trading halves with the partner lane (see mlp_fused_wide_bf16_kernel)
+                __bf16* op = ln_out + mrow * (long long)ld_out + 8 * hh;
 #pragma unroll
                 for (int t = 0; t < Cfg::kTiles; ++t)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint2 o;
-                        o.x = pack_bf16((acc[t][4 * q + 0] - mean) * rstd, (acc[t][4 * q + 1] - mean) * rstd);
-                        o.y = pack_bf16((acc[t][4 * q + 2] - mean) * rstd, (acc[t][4 * q + 3] - mean) * rstd);
-                        *reinterpret_cast<uint2*>(op + 32 * t + 8 * q) = o;
+                    for (int j = 0; j < 2; ++j) {
+                        unsigned e[2], o[2];
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            e[w] = pack_bf16((acc[t][8 * j + 2 * w] - mean) * rstd, (acc[t][8 * j + 2 * w + 1] - mean) * rstd);
+                            o[w] = pack_bf16((acc[t][8 * j + 4 + 2 * w] - mean) * rstd, (acc[t][8 * j + 4 + 2 * w + 1] - mean) * rstd);
+                            acx_pair_swap(e[w], o[w]);
+                        }
+                        if (valid) *reinterpret_cast<uint4*>(op + 32 * t + 16 * j) = uint4{e[0], e[1], o[0], o[1]};
                     }
-                for (int c = C + 4 * hh; c < ld_out; c += 8)      // zero the K padding of the downsample GEMM's operand rows
-                    *reinterpret_cast<uint2*>(ln_out + mrow * (long long)ld_out + c) = uint2{0u, 0u};
+                if (valid)
+                    for (int c = C + 8 * hh; c < ld_out; c += 16)      // zero the K padding of the downsample GEMM's operand rows
+                        *reinterpret_cast<uint4*>(ln_out + mrow * (long long)ld_out + c) = uint4{0u, 0u, 0u, 0u};
             }
-        } else if (valid) {
+        } else {
 #pragma unroll
             for (int t = 0; t < Cfg::kTiles; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = 32 * t + 8 * q;
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b2s + c + 4 * hh);
-                    float4 v = xr[4 * t + q];
-                    v.x += acc[t][4 * q + 0] + bb.x;
-                    v.y += acc[t][4 * q + 1] + bb.y;
-                    v.z += acc[t][4 * q + 2] + bb.z;
-                    v.w += acc[t][4 * q + 3] + bb.w;
-                    acx_st4<ABF>(x, mrow * C + 4 * hh + c, v);
+                for (int j = 0; j < 2; ++j) {
+                    float4 v[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int q = 2 * j + i;
+                        const f32x4 bb = *reinterpret_cast<const f32x4*>(b2s + 32 * t + 8 * q + 4 * hh);
+                        v[i] = xr[4 * t + q];
+                        v[i].x += acc[t][4 * q + 0] + bb.x;
+                        v[i].y += acc[t][4 * q + 1] + bb.y;
+                        v[i].z += acc[t][4 * q + 2] + bb.z;
+                        v[i].w += acc[t][4 * q + 3] + bb.w;
+                    }
+                    if constexpr (ABF) {
+                        unsigned e[2] = {acx_pack_bf16x2(v[0].x, v[0].y), acx_pack_bf16x2(v[0].z, v[0].w)};
+                        unsigned o[2] = {acx_pack_bf16x2(v[1].x, v[1].y), acx_pack_bf16x2(v[1].z, v[1].w)};
+                        acx_pair_swap(e[0], o[0]);
+                        acx_pair_swap(e[1], o[1]);
+                        if (valid)
+                            *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(x) + mrow * C + 8 * hh + 32 * t + 16 * j) = uint4{e[0], e[1], o[0], o[1]};
+                    } else if (valid) {
+                        acx_st4<false>(x, mrow * C + 4 * hh + 32 * t + 16 * j, v[0]);
+                        acx_st4<false>(x, mrow * C + 4 * hh + 32 * t + 16 * j + 8, v[1]);
+                    }
                 }
         }
     }
