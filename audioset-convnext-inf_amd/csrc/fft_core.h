@@ -65,6 +65,15 @@ ACX_HD int fft512_pass(cf* v, int j, int Ns, const cf* tw1024) {
     return (j / Ns) * Ns * 8 + k;
 }
 
+// The same pass with the lane's seven twiddles already fetched: twr[r - 1] = tw1024[2 (j % Ns) (64 / Ns) r], r = 1..7
+// (they depend on the lane and the pass only, not on the frame: the kernel keeps them in registers).
+ACX_HD int fft512_pass_tw(cf* v, int j, int Ns, const cf* twr) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = cf_mul(v[r], twr[r - 1]);
+    fft8(v);
+    return (j / Ns) * Ns * 8 + (j % Ns);
+}
+
 // Padded index of complex element i in the LDS exchange buffers: one pad slot every 8 elements.  Turns the
 // 8- and 16-way bank conflicts of the radix-8 scatter (strides of 64 B and 512 B) into conflict-free
 // (72-B / 576-B strides); the buffers hold 512 + 64 slots.
@@ -80,6 +89,17 @@ ACX_HD cf rfft1024_bin(const cf* Z, int k, const cf* tw1024) {
     cf d = cf_make(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
     cf o = cf_mul_negi(d);
     return cf_add(e, cf_mul(tw1024[k], o));
+}
+
+// Bin k of the real FFT with the split twiddle tw1024[k] passed in (see rfft1024_bin)
+ACX_HD cf rfft1024_bin_tw(const cf* Z, int k, cf twk) {
+    cf a = Z[fft_pad(k & 511)];
+    cf b = Z[fft_pad((512 - k) & 511)];
+    b.y = -b.y;
+    cf e = cf_make(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+    cf d = cf_make(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+    cf o = cf_mul_negi(d);
+    return cf_add(e, cf_mul(twk, o));
 }
 
 // reflect padding without edge repeat (F.pad mode="reflect"): padded index p -> source index

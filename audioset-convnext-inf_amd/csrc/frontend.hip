@@ -58,6 +58,21 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 #pragma unroll
     for (int r = 0; r < 8; ++r) hw[r] = *reinterpret_cast<const float2*>(hann + 2 * (lane + 64 * r));
     __syncthreads();
+    // The twiddles of the two exchange passes and of the real split depend on the lane only: 22 complex registers instead
+    // of 22 LDS reads per frame whose strides (128 r bytes in pass Ns = 8) were this kernel's bank conflicts.
+    cf tw8[7], tw64[7], twk[8];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+        tw8[r - 1] = lds.tw[2 * ((lane % 8) * 8) * r];
+        tw64[r - 1] = lds.tw[2 * lane * r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) twk[r] = lds.tw[lane + 64 * r];
+    const cf tw512 = lds.tw[512];
+    // A wave works on its own frame in its own two buffers; the LDS serves one wave's accesses in issue order, so between
+    // a wave's writes and its reads of other lanes' data nothing but the compiler has to be held back: no workgroup
+    // barrier in the frame loop (the four waves used to move in lockstep through four of them per frame).
+#define ACX_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
     const long long per_iter = (long long)gridDim.x * kFrontWaves;
     const long long iters = (nframes + per_iter - 1) / per_iter;
@@ -90,35 +105,37 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         // pass Ns=1 straight from registers, then two LDS-exchange passes
         cf* bufA = lds.buf[wave][0];
         cf* bufB = lds.buf[wave][1];
+        ACX_WAVE_LDS_SYNC();        // the previous frame's reads of bufA / P are done
         int dst = fft512_pass(v, lane, 1, lds.tw);
 #pragma unroll
         for (int r = 0; r < 8; ++r) bufA[fft_pad(dst + r)] = v[r];
-        __syncthreads();
+        ACX_WAVE_LDS_SYNC();
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = bufA[fft_pad(lane + 64 * r)];
-        dst = fft512_pass(v, lane, 8, lds.tw);
+        dst = fft512_pass_tw(v, lane, 8, tw8);
 #pragma unroll
         for (int r = 0; r < 8; ++r) bufB[fft_pad(dst + r * 8)] = v[r];
-        __syncthreads();
+        ACX_WAVE_LDS_SYNC();
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = bufB[fft_pad(lane + 64 * r)];
-        dst = fft512_pass(v, lane, 64, lds.tw);
+        dst = fft512_pass_tw(v, lane, 64, tw64);
+        ACX_WAVE_LDS_SYNC();        // every lane has read bufA's first-pass data before it is rewritten
 #pragma unroll
         for (int r = 0; r < 8; ++r) bufA[fft_pad(dst + r * 64)] = v[r];
-        __syncthreads();
+        ACX_WAVE_LDS_SYNC();
         // power spectrum, 513 bins
-        float* P = reinterpret_cast<float*>(bufB);       // bufB was last read before the barrier above
+        float* P = reinterpret_cast<float*>(bufB);       // bufB was last read before the wait above
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             int k = lane + 64 * r;
-            cf X = rfft1024_bin(bufA, k, lds.tw);
+            cf X = rfft1024_bin_tw(bufA, k, twk[r]);
             P[k] = X.x * X.x + X.y * X.y;
         }
         if (lane == 0) {
-            cf X = rfft1024_bin(bufA, 512, lds.tw);
+            cf X = rfft1024_bin_tw(bufA, 512, tw512);
             P[512] = X.x * X.x + X.y * X.y;
         }
-        __syncthreads();
+        ACX_WAVE_LDS_SYNC();
         // banded mel filter + dB + bn0
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -135,8 +152,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
             int m = lane + 64 * i;
             if (valid && m < kMels) out[f * kMels + m] = fmaf(db, msc[i], msh[i]);
         }
-        // bufA / P are rewritten only after the next iteration's first barrier
+        // bufA / P are rewritten only after the next iteration's first wait
     }
+#undef ACX_WAVE_LDS_SYNC
 }
 
 
