@@ -7,6 +7,11 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$PREC; rm -rf $O; mkdir -p $O
 cd $R && python bench.py --precision $PREC --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --precision $PREC --steps 20 --warmup 3 --no-cpu-baseline --no-profile > $O/stats.log 2>&1
+# the same on ONE stream (the batch un-split, as bench.py's per-kernel profiled pass runs it): launch durations that do not
+# overlap with the other sub-batch's kernels -- these are the averages that bench.py's roofline objects must agree with
+export ACX_SPLIT_STREAMS=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_onestream -- python3 $R/bench.py --precision $PREC --steps 20 --warmup 3 --no-cpu-baseline --no-profile > $O/stats_onestream.log 2>&1
+unset ACX_SPLIT_STREAMS
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 $R/tools/prof_step.py --precision $PREC > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/tools/prof_step.py --precision $PREC > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/tools/prof_step.py --precision $PREC > $O/pmc_write.log 2>&1
