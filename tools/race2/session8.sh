@@ -8,5 +8,5 @@ run python tools/race2/run_detect.py down1 down2 down3 block0 block1 block2 bloc
 run python tools/race2/run_probe.py block2 3
 run python tools/race_torchvictim.py
 run python bench.py --steps 30 --warmup 5
-ACX_SPLIT_TWO_STREAMS=1 run python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile
+ACX_SPLIT_WAYS=2 run python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile
 cat $O | cut -c1-2500
