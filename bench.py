@@ -18,11 +18,15 @@ times the native f32-MFMA path (`--precision fp32`) and reports it as `native_f3
 weight replica) and includes the one collective of the path -- the RCCL all-gather of the logits --
 in the timed region.  Rank 0 prints ONE JSON line.
 
+The library runs a batch of 16 clips or more as two sub-batches side by side on two streams (acx_forward; `config.sub_batches`
+says how many; ACX_SPLIT_STREAMS=0 turns it off): `value` times the forward as the library runs it.
+
 Extra objects on that line:
   roofline     -- the dominant KERNEL (by device time; the event classes pw1 + pw2 are one kernel,
                   gemm_split_kernel, and are merged): algorithmic FLOPs per launch / average launch duration (HIP
                   events on the launch stream, taken in a separate profiled pass of the same workload so that
-                  event overhead stays out of `value`).  In fp32_split arithmetic every algorithmic fp32 flop is
+                  event overhead stays out of `value`; that pass runs the batch un-split on one stream, so that a launch's
+                  duration is the kernel's own and not its wait for CUs the other sub-batch holds).  In fp32_split arithmetic every algorithmic fp32 flop is
                   three fp16 MFMA flops, so `peak` is the dense fp16 matrix peak / 3 (833 TFLOP/s algorithmic);
                   `frac_executed` (= frac) and `frac_algorithmic_vs_fp16_peak` (algorithmic flops against the
                   raw 2 500 TFLOP/s) are both given.
@@ -48,9 +52,11 @@ CLIP_SAMPLES = 320000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured-achievable)
 MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA, dense (no xf32 on gfx950)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA at the nominal 2.4 GHz
-# In-kernel shader clock of the split GEMMs under load, stamped with s_memtime / s_memrealtime in a diagnostic build
-# (tools/split_lab.hip -DACX_SLAB_CLOCK): the chip holds 1.69 GHz, not 2.4.  Reported next to `frac`
-# as extra information; `peak` and `frac` themselves stay on the nominal figure.
+# Shader clock the chip holds inside the split-fp16 MFMA kernels under load: 1.69 GHz stamped with s_memtime / s_memrealtime
+# in round 1's diagnostic builds, 1.74-1.85 GHz by GRBM_GUI_ACTIVE / duration in round 3's PMC passes
+# (profiles/r03_m_split_pmc_per_kernel.csv); bare fp16 MFMA loops on random operands hold 1.6 GHz
+# (profiles/r03_i_mfma_shape_rates.txt).  Reported next to `frac` as extra information; `peak` and `frac` themselves stay on
+# the nominal 2.4 GHz figure.
 SPLIT_SHADER_CLOCK_GHZ = 1.69
 DIMS, DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
 
