@@ -496,6 +496,174 @@ static int launch_dw_cfg(const BlockW& w, int C, const void* x, void* y, int B, 
     return ACX_OK;
 }
 
+// Stages 2 and 3 (images of 63 x 14 and 31 x 7 pixels per clip, tensors that sit in the Infinity Cache): the streaming
+// kernel above gives a workgroup only 3-6 row tiles there, so its life is mostly ring prologue and store drain (52 / 37 us
+// for 173 / 85 MB).  Here a workgroup takes ONE tile of ROWS output rows x the full width of one clip x one 32-channel slice:
+// the tile with its halo (zero outside the image) is loaded in one go -- one memory round trip in, one out, nothing to
+// stream; the 6 halo rows a tile re-reads come from the cache (W = 14: 22 rows for 16; W = 7 and H <= 32: none).
+// Thread (lane16 = channel pair, g = 0..15 = (row pair, column strip)) computes 2 rows x 7 pixels x 2 channels as in the
+// streaming kernel: an input row (13 reads) feeds both output rows, a kernel row's 7 weights are read once for the pair.
+// W = 7: the two groups of a half-wave read rows two apart -- the row stride is padded by 64 B so that 2 strides = 128
+// (mod 256): disjoint banks; W = 14: they read the two strips of one row, 896 B apart: disjoint as it is.
+// BF: x and y are bf16 (ACX_PREC_BF16_ACT, stage 2): 16-byte loads carry 8 channels, widened on their way into the LDS.
+template <int W, bool BF>
+struct DwTileCfg {
+    static constexpr int kStrips = W / 7;
+    static constexpr int kRows = 32 / kStrips;                   // output rows per tile: 16 groups = row pairs x strips
+    static constexpr int kCols = W + 6;
+    static constexpr int kRowBytes = kCols * 128 + (kStrips == 1 ? 64 : 0);
+    static constexpr int kEPV = BF ? 8 : 4;                      // tensor elements per 16-byte load
+    static constexpr int kQ = kDwSlice / kEPV;                   // 16-byte loads per pixel slice
+    static constexpr int kLoads = ((kRows + 6) * W * kQ + 255) / 256;     // per thread
+    static constexpr size_t kLdsBytes = (size_t)(kRows + 6) * kRowBytes + 49 * 128;
+};
+
+template <int W, bool BF>
+__global__ __launch_bounds__(256, 2) void dwconv7_tile_kernel(const void* __restrict__ x_, void* __restrict__ y_,
+                                                              const float* __restrict__ wt /*[49][C]*/,
+                                                              const float* __restrict__ bias, int H, int C, int tiles_h) {
+    using Cfg = DwTileCfg<W, BF>;
+    using T = typename std::conditional<BF, __bf16, float>::type;
+    constexpr int kCols = Cfg::kCols, kRowBytes = Cfg::kRowBytes, kIn = Cfg::kRows + 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* img = smem;                                                           // [kIn][kCols][32] fp32, rows kRowBytes apart
+    f32x4* wl = reinterpret_cast<f32x4*>(smem + kIn * kRowBytes);               // [49][8]
+    const int slices = C / kDwSlice;
+    int bid = blockIdx.x;
+    const int slice = bid % slices; bid /= slices;
+    const int th = bid % tiles_h;
+    const long long b = bid / tiles_h;
+    const int c0 = slice * kDwSlice;
+    const int r0 = th * Cfg::kRows;                                             // first output row of the tile
+    const int tid = threadIdx.x;
+    const T* xb = reinterpret_cast<const T*>(x_) + b * (long long)H * W * C + c0;
+    // every load of the workgroup is requested before anything waits: the tile's rows r0 - 3 .. r0 + kRows + 2 (rows outside
+    // the image: clamped address, zeroed below) and the 49 x 32 weights
+    f32x4 v[Cfg::kLoads], wreg[2];
+#pragma unroll
+    for (int k = 0; k < Cfg::kLoads; ++k) {
+        int i = tid + 256 * k;
+        if (i >= kIn * W * Cfg::kQ) i = kIn * W * Cfg::kQ - 1;
+        const int q = i % Cfg::kQ, px = i / Cfg::kQ, lr = px / W, cidx = px - lr * W;
+        int r = r0 - 3 + lr;
+        r = r < 0 ? 0 : (r >= H ? H - 1 : r);
+        v[k] = *reinterpret_cast<const f32x4*>(xb + (long long)(r * W + cidx) * C + Cfg::kEPV * q);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int i = tid + 256 * k;
+        if (i >= 49 * 8) i = 49 * 8 - 1;
+        wreg[k] = *reinterpret_cast<const f32x4*>(wt + (i >> 3) * C + c0 + 4 * (i & 7));
+    }
+    // the zero columns left and right of the image while the loads fly (rows outside the image are zeroed with their data)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < kIn * 6 * 8; i += 256) {
+        const int q = i & 7, cb = (i >> 3) % 6, lr = (i >> 3) / 6;
+        const int col = cb < 3 ? cb : W + cb;                                   // 0, 1, 2, W + 3, W + 4, W + 5
+        *reinterpret_cast<f32x4*>(img + lr * kRowBytes + col * 128 + 16 * q) = zero;
+    }
+#pragma unroll
+    for (int k = 0; k < Cfg::kLoads; ++k) {
+        const int i = tid + 256 * k;
+        if (i < kIn * W * Cfg::kQ) {
+            const int q = i % Cfg::kQ, px = i / Cfg::kQ, lr = px / W, cidx = px - lr * W;
+            const int r = r0 - 3 + lr;
+            const bool inside = r >= 0 && r < H;
+            char* dst = img + lr * kRowBytes + (cidx + 3) * 128;
+            if (BF) {                                   // 8 bf16 -> two float4 (channels 8 q .. 8 q + 7)
+                const uint4 u = __builtin_bit_cast(uint4, v[k]);
+                f32x4 lo4 = {acx_bf16_lo(u.x), acx_bf16_hi(u.x), acx_bf16_lo(u.y), acx_bf16_hi(u.y)};
+                f32x4 hi4 = {acx_bf16_lo(u.z), acx_bf16_hi(u.z), acx_bf16_lo(u.w), acx_bf16_hi(u.w)};
+                *reinterpret_cast<f32x4*>(dst + 32 * q) = inside ? lo4 : zero;
+                *reinterpret_cast<f32x4*>(dst + 32 * q + 16) = inside ? hi4 : zero;
+            } else {
+                *reinterpret_cast<f32x4*>(dst + 16 * q) = inside ? v[k] : zero;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 256 * k;
+        if (i < 49 * 8) wl[i] = wreg[k];
+    }
+    __syncthreads();
+
+    const int l16 = tid & 15, g = tid >> 4;
+    const int rp = g / Cfg::kStrips, strip = g % Cfg::kStrips;                  // output rows r0 + 2 rp, + 1; pixels 7 strip .. + 6
+    const f32x2 bv = *reinterpret_cast<const f32x2*>(bias + c0 + 2 * l16);
+    f32x2 acc[2][7];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int p = 0; p < 7; ++p) acc[o][p] = bv;
+    const char* in0 = img + (2 * rp) * kRowBytes + (7 * strip) * 128 + 8 * l16;  // tile row 2 rp = image row r0 + 2 rp - 3
+    const f32x2* wrow = reinterpret_cast<const f32x2*>(wl) + l16;               // tap t at wrow[16 t]
+    // input row 2 rp + ky of the tile meets kernel row ky of output row 2 rp (ky < 7) and kernel row ky - 1 of output row
+    // 2 rp + 1 (ky >= 1).  The six middle rows run as a rolled loop: unrolled, hipcc hoists all 104 row reads and 98 weight
+    // reads to the top and spills.
+#define ACX_DWI_ROW(ky_, do0_, do1_)                                                                            \
+    {                                                                                                           \
+        f32x2 in[13];                                                                                           \
+        _Pragma("unroll") for (int cidx = 0; cidx < 13; ++cidx)                                                 \
+            in[cidx] = *reinterpret_cast<const f32x2*>(in0 + (ky_) * kRowBytes + cidx * 128);                   \
+        if (do0_) {                                                                                             \
+            _Pragma("unroll") for (int kx = 0; kx < 7; ++kx) {                                                  \
+                const f32x2 wv = wrow[16 * (7 * (ky_) + kx)];                                                   \
+                _Pragma("unroll") for (int p = 0; p < 7; ++p) acc[0][p] = in[p + kx] * wv + acc[0][p];          \
+            }                                                                                                   \
+        }                                                                                                       \
+        if (do1_) {                                                                                             \
+            _Pragma("unroll") for (int kx = 0; kx < 7; ++kx) {                                                  \
+                const f32x2 wv = wrow[16 * (7 * ((ky_) - 1) + kx)];                                             \
+                _Pragma("unroll") for (int p = 0; p < 7; ++p) acc[1][p] = in[p + kx] * wv + acc[1][p];          \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    ACX_DWI_ROW(0, true, false)
+#pragma nounroll
+    for (int ky = 1; ky < 7; ++ky) ACX_DWI_ROW(ky, true, true)
+    ACX_DWI_ROW(7, false, true)
+#undef ACX_DWI_ROW
+    T* yb = reinterpret_cast<T*>(y_) + b * (long long)H * W * C + c0 + 2 * l16;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int r = r0 + 2 * rp + o;
+        if (r < H) {
+#pragma unroll
+            for (int p = 0; p < 7; ++p) {
+                T* dst = yb + (long long)(r * W + 7 * strip + p) * C;
+                if (BF) *reinterpret_cast<unsigned*>(dst) = acx_pack_bf16x2(acc[o][p].x, acc[o][p].y);
+                else *reinterpret_cast<f32x2*>(dst) = acc[o][p];
+            }
+        }
+    }
+}
+
+// ONE tile per short-lived workgroup.  Measured against long-lived workgroups walking runs of ~6 tiles with the next tile's
+// rows prefetched into registers (one round of 512 workgroups): 47 vs 56 us per stage-2 launch at B = 64 -- with two
+// workgroups per CU the hardware overlaps one's load phase with the other's arithmetic better than a software pipeline with
+// two barriers per tile does.
+template <int W, bool BF>
+static int launch_dw_tile(const BlockW& w, int C, const void* x, void* y, int B, int H, hipStream_t s) {
+    using Cfg = DwTileCfg<W, BF>;
+    const int tiles_h = (H + Cfg::kRows - 1) / Cfg::kRows;
+    const long long per_clip = (long long)tiles_h * (C / kDwSlice);
+    const long long max_b = 0x3fffffffll / per_clip;           // grid limit: longer batches in chunks of clips
+    if (B > max_b) {
+        for (long long b0 = 0; b0 < B; b0 += max_b) {
+            const int nb = (int)((B - b0) < max_b ? (B - b0) : max_b);
+            const long long off = b0 * (long long)H * W * C * (BF ? 2 : 4);
+            ACX_TRY((launch_dw_tile<W, BF>(w, C, reinterpret_cast<const char*>(x) + off, reinterpret_cast<char*>(y) + off, nb, H, s)));
+        }
+        return ACX_OK;
+    }
+    static DeviceOnce once;
+    ACX_TRY(set_max_dynamic_lds(once, &dwconv7_tile_kernel<W, BF>, Cfg::kLdsBytes));
+    dwconv7_tile_kernel<W, BF><<<dim3((unsigned)(B * per_clip)), dim3(256), Cfg::kLdsBytes, s>>>(x, y, w.dw, w.dwb, H, C, tiles_h);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
 int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, float* stats, int B, int H,
                   int W, hipStream_t s, bool act_bf16) {
     if (act_bf16 && stats) ACX_FAIL(ACX_ERR_STATE, "dwconv7: row statistics are computed from fp32 activations only");
@@ -505,8 +673,10 @@ int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, fl
         switch (W) {
             case 56: rc = act_bf16 ? launch_dw_cfg<28, 8, true>(w, C, x, y, B, H, W, s) : launch_dw_cfg<28, 8, false>(w, C, x, y, B, H, W, s); break;
             case 28: rc = act_bf16 ? launch_dw_cfg<28, 8, true>(w, C, x, y, B, H, W, s) : launch_dw_cfg<28, 8, false>(w, C, x, y, B, H, W, s); break;
-            case 14: rc = act_bf16 ? launch_dw_cfg<14, 16, true>(w, C, x, y, B, H, W, s) : launch_dw_cfg<14, 16, false>(w, C, x, y, B, H, W, s); break;
-            case 7: rc = act_bf16 ? launch_dw_cfg<7, 32, true>(w, C, x, y, B, H, W, s) : launch_dw_cfg<7, 32, false>(w, C, x, y, B, H, W, s); break;   // 31x7 image: one step
+            // stages 2 and 3: one row tile of one clip per workgroup (cache-resident tensors; the streaming kernel's long-lived
+            // workgroups pay off only where every input row must come from HBM exactly once)
+            case 14: rc = act_bf16 ? launch_dw_tile<14, true>(w, C, x, y, B, H, s) : launch_dw_tile<14, false>(w, C, x, y, B, H, s); break;
+            case 7: rc = act_bf16 ? launch_dw_tile<7, true>(w, C, x, y, B, H, s) : launch_dw_tile<7, false>(w, C, x, y, B, H, s); break;
             default: ACX_FAIL(ACX_ERR_SHAPE, "dwconv7: unsupported width %d (expected 56/28/14/7)", W);
         }
         ACX_TRY(rc);
