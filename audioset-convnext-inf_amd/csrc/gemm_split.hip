@@ -22,6 +22,8 @@
 // foreign wave can be co-resident with its MFMA loop (packed-FP32 VALU work of a co-resident wave goes wrong next to
 // it on this platform -- tools/race2/).  A k-tile is only 2 x TM*TN*3 MFMAs of 32 cycles, so
 // the pipeline is deeper than the fp32 kernel's: B tile t+2 and A tiles t+2, t+3 are in flight while tile t is multiplied.
+#include <cstdlib>
+
 #include "acx_internal.h"
 #include "split_math.h"
 
@@ -330,6 +332,280 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
     }
 }
 
+// The same GEMM on v_mfma_f32_16x16x32_f16 (round 3).  Under MFMA load the chip holds a higher clock on this shape than
+// on 32x32x16 at equal cycles per flop (MI355X_MICROARCH.md 'DVFS give-back' item 7; profiles/r03_i_mfma_shape_rates.txt:
+// bare loops on random operands +5..10 % TFLOP/s), and a timing-only substitution in this kernel took 5-7 % off its
+// launches.  Same tiles (256 x 192 x 32, 4 x 2 waves of 64 x 96), same LDS images, same LDS-DMA schedule; what changes:
+//   * a 16x16x32 MFMA contracts the WHOLE 32-k LDS row of 16 rows: lane l reads row l & 15, block l >> 4 (hi chunk
+//     2 (l >> 4), lo chunk + 1, XOR (row >> 1) & 7 as the DMA wrote it: 16 rows x 4 blocks land in distinct banks);
+//   * a k-tile is ONE step of 3 x 4 x 6 = 72 MFMAs of 16 cycles.  It runs as two halves over the weight blocks (n blocks
+//     0-2, then 3-5) so that the fragment registers still rotate: the activation fragments (4 blocks x hi / lo) live for the
+//     whole tile and are double-buffered (A0 / A1, the loop is unrolled by two), the weight fragments of a half are re-read
+//     for the next tile as soon as their half is done.  208 of the 256 registers: 96 accumulators, 64 + 48 fragments;
+//   * D = W A^T tile: lane l holds m = l & 15, n = 4 (l >> 4) .. + 3 -- again four consecutive n per lane (16-byte
+//     accesses); the two lanes l, l + 16 that share an S16 block of 8 n trade halves with v_permlane16_swap.
+template <int EPI, int GATHER>
+__global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
+    constexpr int kBM = 256, BN = 192, WN = 2, NW = 8;
+    constexpr int MI = 4, NJ = 6;                                         // 16-row blocks of a wave's 64 x 96 tile
+    constexpr int A_TILE = kBM * kSRowBytes, B_TILE = BN * kSRowBytes;
+    constexpr int A_DMA = kBM / (8 * NW), B_DMA = BN / (8 * NW);          // 4 + 3 one-KB pieces per wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + 3 * A_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+    ACX_CLAIM_VGPR(255);          // CU-exclusive: 8 waves x 256 registers
+    long long lid = blockIdx.x;
+    {   // XCD-contiguous tile order (see gemm.hip)
+        const long long nwg = gridDim.x, per = (nwg + 7) >> 3, full = nwg - (per - 1) * 8;
+        const long long xcd = lid & 7, k = lid >> 3;
+        lid = (xcd < full ? xcd * per : full * per + (xcd - full) * (per - 1)) + k;
+    }
+    const int tile_n = (int)(lid % p.tiles_n);
+    const long long tile_m = lid / p.tiles_n;
+    const long long m0 = tile_m * kBM;
+    const int n0 = tile_n * BN;
+
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const char* a_src[A_DMA];
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i) {
+        const int row = A_DMA * 8 * wave + 8 * i + prow;
+        const int chunk = pchunk ^ ((row >> 1) & 7);
+        long long m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        if (GATHER) {
+            const int wo = (int)(m % p.Wo);
+            const long long t = m / p.Wo;
+            const int ho = (int)(t % p.Ho);
+            const long long b = t / p.Ho;
+            a_src[i] = p.A + (((b * p.H + 2 * ho) * p.W + 2 * wo) * p.C) * 4 + 16 * chunk;
+        } else {
+            a_src[i] = p.A + m * p.K * 4 + 16 * chunk;
+        }
+    }
+    const char* b_src[B_DMA];
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i) {
+        const int row = B_DMA * 8 * wave + 8 * i + prow;
+        const int chunk = pchunk ^ ((row >> 1) & 7);
+        b_src[i] = p.Wt + (long long)(n0 + row) * p.K * 4 + 16 * chunk;
+    }
+    char* a_dst = As + A_DMA * 8 * wave * kSRowBytes;
+    char* b_dst = Bs + B_DMA * 8 * wave * kSRowBytes;
+    auto a_koff = [&](int k0) -> long long {        // byte offset of k-tile k0 inside an A row
+        if (GATHER) {
+            const int qd = k0 / p.C;
+            return ((long long)((qd >> 1) * p.W + (qd & 1)) * p.C + (k0 - qd * p.C)) * 4;
+        }
+        return (long long)k0 * 4;
+    };
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int sw = (l15 >> 1) & 7;
+    const int foff_hi = l15 * kSRowBytes + (((2 * g4) ^ sw) << 4);
+    const int foff_lo = l15 * kSRowBytes + (((2 * g4 + 1) ^ sw) << 4);
+    const int a_frag_off = wm * 64 * kSRowBytes;
+    const int b_frag_off = wn * 96 * kSRowBytes;
+#define ACX_H8(x) __builtin_bit_cast(h8, x)
+#define ACX_RD_A(F, abase)                                                                             \
+    {   _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                               \
+            F[i][0] = *reinterpret_cast<const f32x4*>((abase) + i * 16 * kSRowBytes + foff_hi);        \
+            F[i][1] = *reinterpret_cast<const f32x4*>((abase) + i * 16 * kSRowBytes + foff_lo); } }
+#define ACX_RD_B(F, bbase, j0)                                                                         \
+    {   _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                \
+            F[j][0] = *reinterpret_cast<const f32x4*>((bbase) + ((j0) + j) * 16 * kSRowBytes + foff_hi); \
+            F[j][1] = *reinterpret_cast<const f32x4*>((bbase) + ((j0) + j) * 16 * kSRowBytes + foff_lo); } }
+    // term 0: W lo x A hi, 1: W hi x A lo, 2: W hi x A hi; term-major: MFMAs on one accumulator are 12 instructions apart
+#define ACX_MFMA16(AF, BF, j0, term, i, j)                                                             \
+    acc[i][(j0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ACX_H8(BF[j][(term) == 0 ? 1 : 0]),     \
+                                                              ACX_H8(AF[i][(term) == 1 ? 1 : 0]), acc[i][(j0) + j], 0, 0, 0);
+#define ACX_MFMA_HALF(AF, BF, j0)                                                                      \
+    {   _Pragma("unroll") for (int term = 0; term < 3; ++term)                                         \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) { ACX_MFMA16(AF, BF, j0, term, i, j) } }
+    // the same with the LDS-DMA pieces threaded in, one piece behind every second MFMA: first the B pieces of tile t+2,
+    // then -- behind one fence -- the A pieces of tile t+3 (the counted wait at the next barrier relies on this order)
+#define ACX_MFMA_HALF_DMA(AF, BF, j0, koffA, aslot, k0B, bslot)                                        \
+    {   _Pragma("unroll") for (int term = 0; term < 3; ++term)                                         \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                \
+            const int mc = (term * MI + i) * 3 + j;                                                    \
+            if ((mc & 1) == 0) {                                                                       \
+                const int pc = mc >> 1;                                                                \
+                if (pc == B_DMA) __builtin_amdgcn_sched_barrier(0);                                    \
+                if (pc < B_DMA) lds_dma16_s(b_src[pc] + (k0B), b_dst + (bslot) * B_TILE + pc * 8 * kSRowBytes); \
+                else if (pc < A_DMA + B_DMA)                                                           \
+                    lds_dma16_s(a_src[pc - B_DMA] + (koffA), a_dst + (aslot) * A_TILE + (pc - B_DMA) * 8 * kSRowBytes); \
+            }                                                                                          \
+            ACX_MFMA16(AF, BF, j0, term, i, j)                                                         \
+        } }
+#define ACX_DMA_A(koffA, aslot)                                                                        \
+    {   _Pragma("unroll") for (int i = 0; i < A_DMA; ++i)                                              \
+            lds_dma16_s(a_src[i] + (koffA), a_dst + (aslot) * A_TILE + i * 8 * kSRowBytes); }
+#define ACX_DMA_B(k0B, bslot)                                                                          \
+    {   _Pragma("unroll") for (int i = 0; i < B_DMA; ++i)                                              \
+            lds_dma16_s(b_src[i] + (k0B), b_dst + (bslot) * B_TILE + i * 8 * kSRowBytes); }
+#define ACX_TOUCH_A(F) { _Pragma("unroll") for (int i = 0; i < MI; ++i) { asm volatile("" :: "v"(F[i][0])); asm volatile("" :: "v"(F[i][1])); } }
+#define ACX_TOUCH_B(F) { _Pragma("unroll") for (int j = 0; j < 3; ++j) { asm volatile("" :: "v"(F[j][0])); asm volatile("" :: "v"(F[j][1])); } }
+
+    const int nk = p.K / kSBK;                                             // even, >= 2 (checked by the launcher)
+    auto ktile = [&](int t) { return (t < nk ? t : nk - 1) * kSBK; };      // past the end: re-request the last tile
+    ACX_DMA_A(a_koff(0), 0)
+    ACX_DMA_B(0LL, 0)
+    __syncthreads();
+    ACX_DMA_B((long long)ktile(1) * 4, 1)
+    ACX_DMA_A(a_koff(ktile(1)), 1)
+    ACX_DMA_A(a_koff(ktile(2)), 2)
+    f32x4 A0[MI][2], A1[MI][2], BL[3][2], BH[3][2];
+    {
+        const char* ab = As + a_frag_off;
+        const char* bb = Bs + b_frag_off;
+        ACX_RD_A(A0, ab)
+        ACX_RD_B(BL, bb, 0)
+        ACX_RD_B(BH, bb, 3)
+    }
+    // steady state, tile t (A slot t % 3, B slot t & 1), activation fragments AC (this tile) / AN (the next one):
+    //   MFMA half 0 | counted wait + barrier (tile t+1 landed, tile t read by every wave) | rd A(t+1), B 0-2 (t+1) |
+    //   MFMA half 1 threaded with DMA B(t+2) -> B slot of t, then DMA A(t+3) -> A slot of t | rd B 3-5 (t+1)
+    int a_cur = 0;
+#define ACX_BODY(kt_, AC, AN)                                                                          \
+    {                                                                                                  \
+        const int a_nxt = a_cur == 2 ? 0 : a_cur + 1;                                                  \
+        const char* abn = As + a_nxt * A_TILE + a_frag_off;                                            \
+        const char* bbn = Bs + (((kt_) + 1) & 1) * B_TILE + b_frag_off;                                \
+        const long long kb = (long long)ktile((kt_) + 2) * 4;                                          \
+        const long long ka = a_koff(ktile((kt_) + 3));                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        ACX_MFMA_HALF(AC, BL, 0)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        ACX_TOUCH_B(BH)                                                                                \
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_DMA) : "memory");                                  \
+        __builtin_amdgcn_s_barrier();                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        ACX_RD_A(AN, abn)                                                                              \
+        ACX_RD_B(BL, bbn, 0)                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        ACX_MFMA_HALF_DMA(AC, BH, 3, ka, a_cur, kb, (kt_) & 1)                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        ACX_TOUCH_A(AN)                                                                                \
+        ACX_TOUCH_B(BL)                                                                                \
+        ACX_RD_B(BH, bbn, 3)                                                                           \
+        a_cur = a_nxt;                                                                                 \
+    }
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+        ACX_BODY(kt, A0, A1)
+        ACX_BODY(kt + 1, A1, A0)
+    }
+    ACX_BODY(kt, A0, A1)                  // kt = nk - 2: the last tile's fragments land in A1 / BL / BH
+    ACX_MFMA_HALF(A1, BL, 0)
+    ACX_MFMA_HALF(A1, BH, 3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the repeated requests of the last iterations: nothing may still be writing the LDS when the workgroup ends
+#undef ACX_BODY
+#undef ACX_RD_A
+#undef ACX_RD_B
+#undef ACX_MFMA16
+#undef ACX_MFMA_HALF
+#undef ACX_MFMA_HALF_DMA
+#undef ACX_DMA_A
+#undef ACX_DMA_B
+#undef ACX_TOUCH_A
+#undef ACX_TOUCH_B
+#undef ACX_H8
+
+    // ---- epilogues: lane (l15, g4) owns row m = m0 + 64 wm + 16 i + l15, columns nb + 4 g4 .. + 3 of block (i, j) ------
+    const float sinv = p.sinv;
+    if (EPI == 1) {
+        GeluConsts gk;          // GELU of v = a * sinv, result x p.hscale (see split_math.h)
+        gk.ps = 0.3275911f * 0.70710678f * sinv;
+        gk.cq = 0.84932180f * sinv;
+        gk.ca = -0.5f * sinv * p.hscale;
+        gk.cb = sinv * p.hscale;
+        const float binv = 1.0f / sinv;     // a power of two
+        // One S16 block (8 n) = [hi x8][lo x8] is shared by the lanes (g4, g4 ^ 1) of a pixel row: after a permlane16
+        // swap the even lane holds all 8 hi halves and the odd lane all 8 lo halves -> one 16-B store each.
+        char* outb = reinterpret_cast<char*>(p.out);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const long long m = m0 + wm * 64 + i * 16 + l15;
+            const bool ok = m < p.M;
+            char* orow = outb + (ok ? m : 0) * p.N * 4;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nb = n0 + wn * 96 + j * 16;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * g4);
+                unsigned xh[2], xl[2];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {      // acc holds v / sinv - bias / sinv: add the pre-scaled bias first
+                    f32x2 a2, av, t, ex, g;
+                    a2.x = acc[i][j][2 * e2] + b4[2 * e2] * binv;
+                    a2.y = acc[i][j][2 * e2 + 1] + b4[2 * e2 + 1] * binv;
+                    gelu_piece1(a2, gk, av, t, ex);
+                    gelu_piece2(a2, av, t, ex, gk, g);
+                    gelu_piece3(g, xh[e2], xl[e2]);
+                }
+                // even rows of 16 lanes: (own hi, partner hi); odd rows: (partner lo, own lo)
+                auto r0 = __builtin_amdgcn_permlane16_swap(xh[0], xl[0], false, false);
+                auto r1 = __builtin_amdgcn_permlane16_swap(xh[1], xl[1], false, false);
+                uint4 o;
+                o.x = r0[0]; o.y = r1[0]; o.z = r0[1]; o.w = r1[1];
+                if (ok) *reinterpret_cast<uint4*>(orow + (long long)(nb + 8 * (g4 >> 1)) * 4 + 16 * (g4 & 1)) = o;
+            }
+        }
+    } else {
+        float* outf = reinterpret_cast<float*>(p.out);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const long long m = m0 + wm * 64 + i * 16 + l15;
+            const bool ok = m < p.M;
+            const long long row = (ok ? m : 0) * p.N;
+            f32x4 rv[NJ];
+            if (EPI == 2) {       // all residual loads of the row in flight before the first store
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) rv[j] = *reinterpret_cast<const f32x4*>(p.resid + row + n0 + wn * 96 + j * 16 + 4 * g4);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nb = n0 + wn * 96 + j * 16;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * g4);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(acc[i][j][e], sinv, b4[e]);
+                    if (EPI == 2) v[e] += rv[j][e];
+                }
+                if (ok) *reinterpret_cast<f32x4*>(outf + row + nb + 4 * g4) = v;
+            }
+        }
+    }
+}
+
+template <int EPI, int GATHER>
+static int launch_s16_cfg(const GemmSParams& p0, hipStream_t s) {
+    GemmSParams p = p0;
+    p.tiles_n = p.N / 192;
+    const long long tiles_m = (p.M + 255) / 256;
+    const long long blocks = tiles_m * p.tiles_n;
+    if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: grid too large");
+    constexpr size_t lds = kCuLdsBytes;          // all of it: CU-exclusive
+    static DeviceOnce once;
+    ACX_TRY(set_max_dynamic_lds(once, &gemm_split16_kernel<EPI, GATHER>, lds));
+    gemm_split16_kernel<EPI, GATHER><<<dim3((unsigned)blocks), dim3(512), lds, s>>>(p);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
 template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
 static int launch_s_cfg(const GemmSParams& p0, hipStream_t s) {
     GemmSParams p = p0;
@@ -350,7 +626,11 @@ template <int EPI, int GATHER>
 static int launch_s_bn(const GemmSParams& p, hipStream_t s) {
     // every N of the model (192, 384, 768, 1536, 3072) is a multiple of 192: 256 x 192 tiles -- 36 MFMAs per barrier and
     // the fewest operand bytes per flop through the LDS-DMA path; 256 x 128 for other multiples of 128
-    if (p.N % 192 == 0) return launch_s_cfg<256, 192, 4, 2, EPI, GATHER>(p, s);
+    if (p.N % 192 == 0) {
+        static const bool old_shape = [] { const char* e = std::getenv("ACX_GEMM_32X32"); return e && e[0] == '1'; }();   // A/B switch
+        if ((p.K / kSBK) % 2 == 0 && !old_shape) return launch_s16_cfg<EPI, GATHER>(p, s);
+        return launch_s_cfg<256, 192, 4, 2, EPI, GATHER>(p, s);
+    }
     if (p.N % 128 == 0) return launch_s_cfg<256, 128, 4, 2, EPI, GATHER>(p, s);
     ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: N=%d is not a multiple of 192 or 128", p.N);
 }
