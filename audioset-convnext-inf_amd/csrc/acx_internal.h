@@ -77,6 +77,13 @@ __device__ __forceinline__ void acx_pair_swap(unsigned& a, unsigned& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     a = r[0]; b = r[1];
 }
+// The same between lanes l and l ^ 16 (v_permlane16_swap_b32: the odd rows of 16 lanes of a trade with the even rows of b):
+// the lane of the EVEN row ends up with (its own a, the odd row's a), the lane of the ODD row with (the even row's b, its
+// own b) -- the 16x16 MFMA layouts, where the lanes (g4, g4 ^ 1) of a pixel row hold adjacent groups of four channels.
+__device__ __forceinline__ void acx_pair_swap16(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
 
 // ---- bf16 activations in HBM (ACX_PREC_BF16_ACT, stages 0-2): packed pairs, round to nearest even (v_cvt_pk_bf16_f32) ---
 typedef __bf16 acx_bf2 __attribute__((ext_vector_type(2)));

@@ -398,13 +398,14 @@ static int finalize_impl(acx_ctx* c) {
                                         h1.data() + ((size_t)(32 * k + r) * C * 4 + (size_t)p * 16) / 2, 16);
                         }
                     // W2 image of chunk k: row = out channel (128 B = 8 chunks); content chunk 2b (hi) / 2b + 1 (lo) of
-                    // block b = 2s' + h holds hidden units 32k + 16s' + 4h + 8(jj >> 2) + (jj & 3), at position ^ ((ch >> 1) & 7)
+                    // block b (= k block g4 of the 16x16x32 MFMA) holds hidden units 32k + 16(jj >> 2) + 4b + (jj & 3) -- the order
+                    // in which a lane's accumulators of phase 1 become its B operand of phase 2 --, at position ^ ((ch >> 1) & 7)
                     uint16_t* w2img = st.data() + (size_t)(k == nch - 1 ? 2 * nch - 1 : 2 * k + 2) * seg;
                     for (int ch = 0; ch < C; ++ch)
                         for (int b = 0; b < 4; ++b) {
                             uint16_t hi8[8], lo8[8];
                             for (int jj = 0; jj < 8; ++jj) {
-                                const int u = 32 * k + 16 * (b >> 1) + 4 * (b & 1) + 8 * (jj >> 2) + (jj & 3);
+                                const int u = 32 * k + 16 * (jj >> 2) + 4 * b + (jj & 3);
                                 const float v = f2[(size_t)ch * 4 * C + u] * bw.w2s_scale;
                                 const _Float16 hi = (_Float16)v;
                                 const _Float16 lo = (_Float16)(v - (float)hi);

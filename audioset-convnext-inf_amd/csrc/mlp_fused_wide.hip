@@ -1,7 +1,17 @@
 // K4fw -- the fused block MLP (LayerNorm -> pwconv1 -> GELU -> pwconv2 -> gamma -> + residual, convnext.py:77-86) in
 // split-fp16 arithmetic for WIDE stages (C = 384): the hidden activation (B H W x 4C, 347 MB per block at B = 64) never
 // exists in memory (hard part 1).  Same transposed dataflow as mlp_fused_split.hip -- a wave owns 32 pixels,
-// the accumulator tile of the first product is the B operand of the second -- re-planned for one wave per SIMD:
+// the accumulator tile of the first product is the B operand of the second -- re-planned for one wave per SIMD.
+//
+// Matrix instruction: v_mfma_f32_16x16x32_f16 (since round 3; 32x32x16 before).  Same flops per cycle, but under MFMA load
+// the chip holds a higher clock on this shape (MI355X_MICROARCH.md 'DVFS give-back' item 7; profiles/r03_i_mfma_shape_rates.txt;
+// same-box A/B of this kernel: -3 % per launch, -2.7 % per forward).  A wave's 32 pixels are two blocks of 16 (pb), a chunk's
+// 32 hidden units two blocks of 16 (hb); lane (l15, g4) is row / column l15 and k block g4 (8 of the 32 k) of every operand:
+//   phase 1   X^T block (hb, pb) [16 hidden x 16 px] += W1c rows 16 hb .. (one fragment, 32 channels) . LN(y)^T block pb
+//   phase 2   out^T block (cb, pb) [16 channels x 16 px] += W2c rows 16 cb .. (one fragment, the chunk's 32 hidden units) . G(pb)
+// A weight fragment feeds both pixel blocks; an accumulator block is 4 registers: lane holds rows 4 g4 .. + 3 of column l15,
+// so the 8 pre-activations of a lane's two X blocks of one pixel block are, as they stand, its 8 k values of phase 2's B
+// operand (k slot 8 g4 + j = hidden unit 16 (j >> 2) + 4 g4 + (j & 3): acx_finalize stores W2c's columns in that order).
 //
 //   registers   the workgroup is CU-exclusive (acx_internal.h): 4 waves x 512 registers.  Per lane: C/2 for the wave's
 //               normalised activations (hi + lo halves, B operand of phase 1), C/2 accumulators of out^T, ~100 working.
@@ -10,12 +20,12 @@
 //               a segment = the [32 x C] (W1) or [C x 32] (W2) S16 image of one chunk, 128 C bytes, already in LDS image
 //               order (XOR swizzle baked in), so the LDS-DMA source of a piece is base + 1 KB x piece + 16 x lane.
 //               LDS holds a ring of three segments: one being multiplied, one landed or landing, one being requested.
-//   schedule    segment 2k-1: phase 1 of chunk k    X^T[32 hidden x 32 px] = W1c . LN(y)^T     3 C/16 MFMAs on Xn
-//               segment 2k  : phase 2 of chunk k-1  out^T[C x 32 px] += W2c . G(k-1)            3 C/16 MFMAs
+//   schedule    segment 2k-1: phase 1 of chunk k    X^T[32 hidden x 32 px] = W1c . LN(y)^T     3 C/16 MFMA pairs (one per pixel block)
+//               segment 2k  : phase 2 of chunk k-1  out^T[C x 32 px] += W2c . G(k-1)            3 C/16 MFMA pairs
 //               GELU + hi/lo split of X(k) -> G(k): 30 single-instruction "nano-steps" per register pair (split_math.h,
 //               gelu_nano), half of the pairs dealt over the MFMAs of segment 2k, the other half over those of segment
 //               2k+1.  One wave per SIMD issues both streams: about five single-issue instructions ride for free behind
-//               a 32x32x16 MFMA, every further one costs ~5 cycles (profiles/r03_d_coissue_table_full.txt), so each MFMA
+//               32 cycles of matrix work (a 32x32x16 MFMA then, a pair of 16x16x32 now), every further one costs ~5 cycles (profiles/r03_d_coissue_table_full.txt), so each MFMA
 //               gap gets at most four slots, fewer where an LDS-DMA piece or the fragment reads of the next unit already
 //               sit in it (WideCfg::gap_free).
 //               The DMA pieces of segment s+2 are threaded through the units of segment s; one counted s_waitcnt vmcnt +
@@ -106,18 +116,19 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hh = lane >> 5;
+    static_assert(PT == 1, "the 16x16x32 form is written for one 32-pixel tile per wave");
+    const int l15 = lane & 15, g4 = lane >> 4;       // 16x16x32 MFMA: lane = (row / column l15, k block g4)
     ACX_CLAIM_VGPR(255);          // CU-exclusive: one wave per SIMD holds the SIMD's whole register file
     ACX_CLAIM_AGPR(255);
     ACX_WSTAMP_DECL
     ACX_WSTAMP(-1)
-    long long mrow[PT];           // this lane's pixel row in each of the wave's pixel tiles
-    bool valid[PT];
+    long long mrow[2];            // this lane's pixel row in each of the wave's two 16-pixel blocks
+    bool valid[2];
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        mrow[pt] = (long long)blockIdx.x * Cfg::kPix + (wave * PT + pt) * 32 + l31;
-        valid[pt] = mrow[pt] < M;
-        if (!valid[pt]) mrow[pt] = M - 1;
+    for (int pb = 0; pb < 2; ++pb) {
+        mrow[pb] = (long long)blockIdx.x * Cfg::kPix + wave * 32 + pb * 16 + l15;
+        valid[pb] = mrow[pb] < M;
+        if (!valid[pb]) mrow[pb] = M - 1;
     }
 
     constexpr int n = Cfg::kChunks;
@@ -138,31 +149,34 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         for (int i = tid; i < 4 * C; i += Cfg::kThreads) b1s[i] = b1[i] * b1scale;
     }
 
-    // ---- this wave's activations: lane (px = l31, half hh) holds channels 16s + 8hh .. +7, s = 0..C/16-1 --------
-    f32x4 acth[PT][Cfg::kSteps], actl[PT][Cfg::kSteps];         // 8 fp16 halves each
+    // ---- this wave's activations: lane (px = l15 of block pb, k block g4) holds channels 32 s + 8 g4 .. + 7, s = 0..C/32-1 ----
+    constexpr int kS32 = C / 32;
+    f32x4 acth[2][kS32], actl[2][kS32];                         // 8 fp16 halves each
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        float a[C / 2];
-        const float* yp = y + mrow[pt] * C + 8 * hh;
+    for (int pb = 0; pb < 2; ++pb) {
+        float a[C / 4];
+        const float* yp = y + mrow[pb] * C + 8 * g4;
 #pragma unroll
-        for (int s = 0; s < Cfg::kSteps; ++s) {
-            const float4 v0 = *reinterpret_cast<const float4*>(yp + 16 * s);
-            const float4 v1 = *reinterpret_cast<const float4*>(yp + 16 * s + 4);
+        for (int s = 0; s < kS32; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(yp + 32 * s);
+            const float4 v1 = *reinterpret_cast<const float4*>(yp + 32 * s + 4);
             a[8 * s + 0] = v0.x; a[8 * s + 1] = v0.y; a[8 * s + 2] = v0.z; a[8 * s + 3] = v0.w;
             a[8 * s + 4] = v1.x; a[8 * s + 5] = v1.y; a[8 * s + 6] = v1.z; a[8 * s + 7] = v1.w;
         }
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < C / 2; ++i) sum += a[i];
+        for (int i = 0; i < C / 4; ++i) sum += a[i];
+        sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float mean = sum * (1.0f / C);
         float d = 0.f;
 #pragma unroll
-        for (int i = 0; i < C / 2; ++i) { const float t = a[i] - mean; d = fmaf(t, t, d); }
+        for (int i = 0; i < C / 4; ++i) { const float t = a[i] - mean; d = fmaf(t, t, d); }
+        d += __shfl_xor(d, 16);
         d += __shfl_xor(d, 32);
         const float sc = kSplitLnScale / sqrtf(d * (1.0f / C) + 1e-6f);
 #pragma unroll
-        for (int s = 0; s < Cfg::kSteps; ++s) {
+        for (int s = 0; s < kS32; ++s) {
             unsigned uh4[4], ul4[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -174,74 +188,74 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
                 uh4[p] = __builtin_bit_cast(unsigned, h);
                 ul4[p] = __builtin_bit_cast(unsigned, l);
             }
-            acth[pt][s] = __builtin_bit_cast(f32x4, uint4{uh4[0], uh4[1], uh4[2], uh4[3]});
-            actl[pt][s] = __builtin_bit_cast(f32x4, uint4{ul4[0], ul4[1], ul4[2], ul4[3]});
+            acth[pb][s] = __builtin_bit_cast(f32x4, uint4{uh4[0], uh4[1], uh4[2], uh4[3]});
+            actl[pb][s] = __builtin_bit_cast(f32x4, uint4{ul4[0], ul4[1], ul4[2], ul4[3]});
         }
     }
 
-    f32x16 acc[PT][C / 32];
+    f32x4 acc[C / 16][2];         // out^T: block cb = 16 out channels x pixel block pb; lane holds channels 16 cb + 4 g4 .. + 3
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt)
+    for (int cb = 0; cb < C / 16; ++cb)
 #pragma unroll
-        for (int t = 0; t < C / 32; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[pt][t][r] = 0.f;
+        for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fragment addresses inside a segment (without the ring offset):
-    //   W1 image: row = hidden unit l31 (4 C bytes = C/4 chunks of 16 B), chunk p = 4 s + 2 hh + pl at position p ^ swz1(l31)
-    //             (pl = 0 hi halves, 1 lo halves; the XOR touches the low 4 (C = 96: 3) bits only)
-    //   W2 image: row = out channel (128 B = 8 chunks), tile t rows 32 t + l31, chunk 2 (2 s' + hh) + pl at position ^ ((l31 >> 1) & 7)
-    int w1off[4][2], w2off[2][2];
+    // fragment addresses inside a segment (without the ring offset) for v_mfma_f32_16x16x32_f16: lane (l15, g4) reads row
+    // l15 of a 16-row block, the 8 k of block g4 of the 32-k step:
+    //   W1 image: row = hidden unit (4 C bytes = C/4 chunks of 16 B), 16-row block hb; chunk p = 8 s32 + 2 g4 + pl at position
+    //             p ^ l15 (pl = 0 hi halves, 1 lo halves; the XOR touches the low 4 bits only: C % 64 == 0)
+    //   W2 image: row = out channel (128 B = 8 chunks), block cb rows 16 cb + l15, chunk 2 g4 + pl at position ^ ((l15 >> 1) & 7)
+    static_assert(C % 64 == 0, "W1 image swizzle");
+    int w1off[2][2], w2off[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) w1off[q][pl] = l31 * (4 * C) + (((4 * q + 2 * hh + pl) ^ Cfg::swz1(l31)) << 4);
+        for (int pl = 0; pl < 2; ++pl) w1off[q][pl] = l15 * (4 * C) + (((8 * q + 2 * g4 + pl) ^ l15) << 4);
 #pragma unroll
-    for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) w2off[sp][pl] = l31 * 128 + (((2 * (2 * sp + hh) + pl) ^ ((l31 >> 1) & 7)) << 4);
+    for (int pl = 0; pl < 2; ++pl) w2off[pl] = l15 * 128 + (((2 * g4 + pl) ^ ((l15 >> 1) & 7)) << 4);
     const GeluK2 gk = gelu_k2(sinv1, hscale);
 
 #define ACX_H8(v_) __builtin_bit_cast(h8, v_)
 #define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
-    // phase-1 unit = k-step s_ of the chunk: chunk 4 s_ + ..: the bits above the XORed four = s_ / 4 -> + 256 B each
-#define ACX_W1_RD(base_, s_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((s_) >> 2) * 256 + w1off[(s_) & 3][pl_]))
-    // MFMA number m_ of a segment is followed (behind a scheduling fence) by its share of the kHalf GELU micro-steps the
-    // segment carries: steps [kHalf m / kMfmas, kHalf (m + 1) / kMfmas) of the half (C = 384: one after every other MFMA,
-    // C = 192: one after each, C = 96: two after each)
+    // phase-1 unit u_ = (32-channel step s32 = u_ >> 1, hidden block hb = u_ & 1): the bits of the chunk index above the XORed
+    // four = s32 >> 1 -> + 256 B each
+#define ACX_W1_RD(base_, u_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) & 1) * (16 * 4 * C) + ((u_) >> 2) * 256 + w1off[((u_) >> 1) & 1][pl_]))
+    // MFMA slot m_ of a segment -- a PAIR of 16x16x32 MFMAs, one per pixel block, 2 x 16 cycles -- is followed (behind a
+    // scheduling fence) by its share of the GELU nano-steps the segment carries (WideCfg::nano_begin / nano_end)
 #define ACX_AFTER_MFMA(HV_, half_, m_)                                                                          \
         ACX_FENCE if constexpr (HV_) { ACX_NANO_RANGE(half_, Cfg::nano_begin(m_), Cfg::nano_end(m_)) } ACX_FENCE
-    // the three terms of a unit, each over the PT pixel tiles (independent accumulators back to back)
-#define ACX_P1_MFMA(s_, ah_, al_)                                                                               \
-        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
-            Xn[pt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[pt_][s_]), Xn[pt_], 0, 0, 0); \
-            if (pt_ == 0 && (s_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (s_) / Cfg::kDmaStride, g2) } \
-            ACX_AFTER_MFMA(HV, 1, (3 * (s_) + 0) * PT + pt_) }                                                  \
-        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
-            Xn[pt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(actl[pt_][s_]), Xn[pt_], 0, 0, 0); \
-            ACX_AFTER_MFMA(HV, 1, (3 * (s_) + 1) * PT + pt_) }                                                  \
-        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
-            Xn[pt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(acth[pt_][s_]), Xn[pt_], 0, 0, 0); \
-            ACX_AFTER_MFMA(HV, 1, (3 * (s_) + 2) * PT + pt_) }
-    // phase-2 unit i = (out tile t = i >> 1, k-step s' = i & 1)
-#define ACX_W2_RD(base_, i_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((i_) >> 1) * 4096 + w2off[(i_) & 1][pl_]))
+#define ACX_M16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ACX_H8(a_), ACX_H8(b_), c_, 0, 0, 0);
+    // the three terms of a unit, each over the two pixel blocks (independent accumulators back to back); X block index = 2 pb + hb
+#define ACX_P1_MFMA(u_, ah_, al_)                                                                               \
+        ACX_M16(al_, acth[0][(u_) >> 1], Xn[(u_) & 1])                                                          \
+        if ((u_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (u_) / Cfg::kDmaStride, g2) }              \
+        ACX_M16(al_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                    \
+        ACX_AFTER_MFMA(HV, 1, 3 * (u_) + 0)                                                                     \
+        ACX_M16(ah_, actl[0][(u_) >> 1], Xn[(u_) & 1])                                                          \
+        ACX_M16(ah_, actl[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                    \
+        ACX_AFTER_MFMA(HV, 1, 3 * (u_) + 1)                                                                     \
+        ACX_M16(ah_, acth[0][(u_) >> 1], Xn[(u_) & 1])                                                          \
+        ACX_M16(ah_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                    \
+        ACX_AFTER_MFMA(HV, 1, 3 * (u_) + 2)
+    // phase-2 unit i_ = block cb of 16 out channels; K = the chunk's 32 hidden units in ONE step
+#define ACX_W2_RD(base_, i_, pl_) (*reinterpret_cast<const f32x4*>((base_) + (i_) * (16 * 128) + w2off[pl_]))
 #define ACX_P2_MFMA(i_, ah_, al_)                                                                               \
-        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
-            acc[pt_][(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(gh[pt_][(i_) & 1]), acc[pt_][(i_) >> 1], 0, 0, 0); \
-            if (pt_ == 0 && (i_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (i_) / Cfg::kDmaStride, g2) } \
-            ACX_AFTER_MFMA(HV, 0, (3 * (i_) + 0) * PT + pt_) }                                                  \
-        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
-            acc[pt_][(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gl[pt_][(i_) & 1]), acc[pt_][(i_) >> 1], 0, 0, 0); \
-            ACX_AFTER_MFMA(HV, 0, (3 * (i_) + 1) * PT + pt_) }                                                  \
-        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
-            acc[pt_][(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(ah_), ACX_H8(gh[pt_][(i_) & 1]), acc[pt_][(i_) >> 1], 0, 0, 0); \
-            ACX_AFTER_MFMA(HV, 0, (3 * (i_) + 2) * PT + pt_) }
-    // nano-steps [from, to) of the kNano that segment half half_ carries: step ng_ belongs to pixel tile ng_ / 120 and is
-    // instruction ng_ % 30 of register pair 4 half_ + (ng_ % 120) / 30 (split_math.h, gelu_nano): pair after pair, in order
+        ACX_M16(al_, gh[0], acc[i_][0])                                                                         \
+        if ((i_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (i_) / Cfg::kDmaStride, g2) }              \
+        ACX_M16(al_, gh[1], acc[i_][1])                                                                         \
+        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 0)                                                                     \
+        ACX_M16(ah_, gl[0], acc[i_][0])                                                                         \
+        ACX_M16(ah_, gl[1], acc[i_][1])                                                                         \
+        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 1)                                                                     \
+        ACX_M16(ah_, gh[0], acc[i_][0])                                                                         \
+        ACX_M16(ah_, gh[1], acc[i_][1])                                                                         \
+        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 2)
+    // nano-steps [from, to) of the kNano that segment half half_ carries: step ng_ is instruction ng_ % 30 of register pair
+    // 4 half_ + ng_ / 30 (split_math.h, gelu_nano): pair after pair, in order.  Pair pr = 4 pb + 2 hb + e covers registers
+    // 2 e, 2 e + 1 of X block 2 pb + hb: hidden units 16 hb + 4 g4 + 2 e, + 1 of pixel block pb
 #define ACX_NANO_RANGE(half_, from_, to_)                                                                       \
         _Pragma("unroll") for (int ng_ = (from_); ng_ < (to_); ++ng_) {                                         \
             const int mt_ = ng_ / (4 * kGeluNano), pr_ = 4 * (half_) + (ng_ % (4 * kGeluNano)) / kGeluNano, st_ = ng_ % kGeluNano; \
-            if (st_ == 0) { gsA.ax = Xv[mt_][2 * pr_]; gsA.ay = Xv[mt_][2 * pr_ + 1]; gelu_nano<0>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]); } \
+            if (st_ == 0) { gsA.ax = Xv[(2 * pr_) >> 2][(2 * pr_) & 3]; gsA.ay = Xv[(2 * pr_) >> 2][((2 * pr_) & 3) + 1]; gelu_nano<0>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]); } \
             else if (st_ == 1) gelu_nano<1>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
             else if (st_ == 2) gelu_nano<2>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
             else if (st_ == 3) gelu_nano<3>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
@@ -274,17 +288,16 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         }
 #define ACX_TOUCH2(h_, l_) asm volatile("" :: "v"(h_), "v"(l_));
 #define ACX_BIAS_INIT(j_)                                                                                       \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j_) + 8 * q + 4 * hh);                 \
-            _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                              \
-                Xn[pt_][4 * q + 0] = bq[0]; Xn[pt_][4 * q + 1] = bq[1]; Xn[pt_][4 * q + 2] = bq[2]; Xn[pt_][4 * q + 3] = bq[3]; } \
+        _Pragma("unroll") for (int hb_ = 0; hb_ < 2; ++hb_) {                                                   \
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j_) + 16 * hb_ + 4 * g4);              \
+            Xn[hb_] = bq; Xn[2 + hb_] = bq;                                                                     \
         }
+    // G of the chunk as the B operand of phase 2: pixel block pb takes pairs 4 pb .. + 3 -- k slot 8 g4 + j of the MFMA is
+    // hidden unit 16 (j >> 2) + 4 g4 + (j & 3) of the chunk; acx_finalize stores W2c's columns in that order
 #define ACX_PACK_G()                                                                                            \
-        _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
-            gh[pt_][0] = __builtin_bit_cast(f32x4, uint4{uh[pt_][0], uh[pt_][1], uh[pt_][2], uh[pt_][3]});      \
-            gh[pt_][1] = __builtin_bit_cast(f32x4, uint4{uh[pt_][4], uh[pt_][5], uh[pt_][6], uh[pt_][7]});      \
-            gl[pt_][0] = __builtin_bit_cast(f32x4, uint4{ul[pt_][0], ul[pt_][1], ul[pt_][2], ul[pt_][3]});      \
-            gl[pt_][1] = __builtin_bit_cast(f32x4, uint4{ul[pt_][4], ul[pt_][5], ul[pt_][6], ul[pt_][7]}); }
+        _Pragma("unroll") for (int pb_ = 0; pb_ < 2; ++pb_) {                                                   \
+            gh[pb_] = __builtin_bit_cast(f32x4, uint4{uh[0][4 * pb_ + 0], uh[0][4 * pb_ + 1], uh[0][4 * pb_ + 2], uh[0][4 * pb_ + 3]}); \
+            gl[pb_] = __builtin_bit_cast(f32x4, uint4{ul[0][4 * pb_ + 0], ul[0][4 * pb_ + 1], ul[0][4 * pb_ + 2], ul[0][4 * pb_ + 3]}); }
     // end of a segment: the pieces requested during it may stay in flight, everything older must have landed, and
     // every wave must be done reading the segment before its ring slot is requested again
 #define ACX_SEG_END(issued_, stamp_)                                                                            \
@@ -296,8 +309,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         ACX_FENCE                                                                                               \
         ACX_WSTAMP(3)
 
-    f32x16 Xn[PT], Xv[PT];        // Xn: pre-activation being accumulated by phase 1; Xv: the previous chunk's, input of the GELU
-    f32x4 gh[PT][2], gl[PT][2];   // G(k - 1): B operand of phase 2, two k-steps, hi / lo halves
+    f32x4 Xn[4], Xv[4];           // X^T blocks 2 pb + hb (16 hidden x 16 pixels each): Xn being accumulated by phase 1; Xv: the previous chunk's, input of the GELU
+    f32x4 gh[2], gl[2];           // G(k - 1): B operand of phase 2 per pixel block, hi / lo halves
     unsigned uh[PT][8], ul[PT][8];
     GeluState2 gsA;
 
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #undef ACX_P1_UNIT
         if constexpr (HV) { ACX_PACK_G() }
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) Xv[pt] = Xn[pt];
+        for (int q = 0; q < 4; ++q) Xv[q] = Xn[q];
         ACX_SEG_END(dma, 1)
     };
     // one phase-2 segment: out^T += W2c . G for the chunk whose G sits in gh / gl, image in ring slot grp_; with_gelu:
@@ -378,14 +391,12 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     grp = grp == 2 ? 0 : grp + 1;
     // the activations are dead from here on: their registers take the residual x of the tile, requested two segments
     // (~2 us) before the epilogue needs it
-    float4 xr[PT][C / 8];
+    f32x4 xr[2][C / 16];
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        const float* xp = x + mrow[pt] * C + 4 * hh;
+    for (int pb = 0; pb < 2; ++pb) {
+        const float* xp = x + mrow[pb] * C + 4 * g4;
 #pragma unroll
-        for (int t = 0; t < C / 32; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xr[pt][4 * t + q] = *reinterpret_cast<const float4*>(xp + 32 * t + 8 * q);
+        for (int cb = 0; cb < C / 16; ++cb) xr[pb][cb] = *reinterpret_cast<const f32x4*>(xp + 16 * cb);
     }
     phase2(std::true_type{}, 2 * n - 2, grp);
     grp = grp == 2 ? 0 : grp + 1;
@@ -406,75 +417,60 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #undef ACX_PACK_G
 #undef ACX_SEG_END
 
-    // ---- epilogue: lane (px, hh), tile t, q: channels 32t + 8q + 4hh .. +3  ->  x = x + out + b2 ---------
+    // ---- epilogue: lane (px = l15 of block pb, g4), block cb: channels 16 cb + 4 g4 .. + 3  ->  x = x + out + b2 ---------
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
+    for (int pb = 0; pb < 2; ++pb) {
     if constexpr (LNOUT) {
         // last block of the stage in the full forward: the only reader of the new x is the LayerNorm in front of the
         // downsample conv (convnext.py:230-235): write its S16 operand instead (see mlp_fused_split.hip)
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < C / 32; ++t) {
+        for (int cb = 0; cb < C / 16; ++cb) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * cb + 4 * g4);
+            const f32x4 v = xr[pb][cb];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = 32 * t + 8 * q;
-                const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
-                const float4 v = xr[pt][4 * t + q];
-                acc[pt][t][4 * q + 0] = v.x + fmaf(acc[pt][t][4 * q + 0], sinv2, bb.x);
-                acc[pt][t][4 * q + 1] = v.y + fmaf(acc[pt][t][4 * q + 1], sinv2, bb.y);
-                acc[pt][t][4 * q + 2] = v.z + fmaf(acc[pt][t][4 * q + 2], sinv2, bb.z);
-                acc[pt][t][4 * q + 3] = v.w + fmaf(acc[pt][t][4 * q + 3], sinv2, bb.w);
-                sum += (acc[pt][t][4 * q + 0] + acc[pt][t][4 * q + 1]) + (acc[pt][t][4 * q + 2] + acc[pt][t][4 * q + 3]);
-            }
+            for (int e = 0; e < 4; ++e) acc[cb][pb][e] = v[e] + fmaf(acc[cb][pb][e], sinv2, bb[e]);
+            sum += (acc[cb][pb][0] + acc[cb][pb][1]) + (acc[cb][pb][2] + acc[cb][pb][3]);
         }
+        sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float mean = sum * (1.0f / C);
         float d = 0.f;
 #pragma unroll
-        for (int t = 0; t < C / 32; ++t)
+        for (int cb = 0; cb < C / 16; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float u = acc[pt][t][r] - mean; d = fmaf(u, u, d); }
+            for (int e = 0; e < 4; ++e) { const float u = acc[cb][pb][e] - mean; d = fmaf(u, u, d); }
+        d += __shfl_xor(d, 16);
         d += __shfl_xor(d, 32);
         const float sc = kSplitLnScale / sqrtf(d * (1.0f / C) + 1e-6f);
-        // lanes (px, 0) and (px, 1) trade halves so that each writes ONE 16-byte piece per block -- the lower lane the 8 hi
-        // halves, the upper lane the 8 lo halves: 32 contiguous bytes per row and store instruction (the rows are cold: 8-byte
-        // pieces cost a read-for-ownership of every sector)
-        char* op = ln_out + mrow[pt] * (long long)(C * 4) + 16 * hh;
+        // an S16 block (8 channels: [8 hi][8 lo]) is shared by the lanes (g4, g4 ^ 1) of a pixel: after a permlane16 swap the
+        // even lane holds all 8 hi halves and the odd lane all 8 lo halves -> one 16-byte store each, 32 contiguous bytes per row
+        char* op = ln_out + mrow[pb] * (long long)(C * 4) + (g4 >> 1) * 32 + 16 * (g4 & 1);
 #pragma unroll
-        for (int t = 0; t < C / 32; ++t) {
+        for (int cb = 0; cb < C / 16; ++cb) {
+            unsigned uhi[2], ulo[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned uhi[2], ulo[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    f32x2 v;
-                    v.x = (acc[pt][t][4 * q + 2 * e] - mean) * sc; v.y = (acc[pt][t][4 * q + 2 * e + 1] - mean) * sc;
-                    const h2 h = __builtin_convertvector(v, h2);
-                    const f32x2 back = __builtin_convertvector(h, f32x2);
-                    const h2 l = __builtin_convertvector(v - back, h2);
-                    uhi[e] = __builtin_bit_cast(unsigned, h);
-                    ulo[e] = __builtin_bit_cast(unsigned, l);
-                    acx_pair_swap(uhi[e], ulo[e]);
-                }
-                // block of channels 32t + 8q .. +7: [8 hi][8 lo]
-                if (valid[pt]) *reinterpret_cast<uint4*>(op + (4 * t + q) * 32) = uint4{uhi[0], uhi[1], ulo[0], ulo[1]};
+            for (int e = 0; e < 2; ++e) {
+                f32x2 v;
+                v.x = (acc[cb][pb][2 * e] - mean) * sc; v.y = (acc[cb][pb][2 * e + 1] - mean) * sc;
+                const h2 h = __builtin_convertvector(v, h2);
+                const f32x2 back = __builtin_convertvector(h, f32x2);
+                const h2 l = __builtin_convertvector(v - back, h2);
+                uhi[e] = __builtin_bit_cast(unsigned, h);
+                ulo[e] = __builtin_bit_cast(unsigned, l);
+                acx_pair_swap16(uhi[e], ulo[e]);
             }
+            if (valid[pb]) *reinterpret_cast<uint4*>(op + cb * 64) = uint4{uhi[0], uhi[1], ulo[0], ulo[1]};
         }
-    } else if (valid[pt]) {
-        float* xp = x + mrow[pt] * C + 4 * hh;
+    } else if (valid[pb]) {
+        float* xp = x + mrow[pb] * C + 4 * g4;
 #pragma unroll
-        for (int t = 0; t < C / 32; ++t) {
+        for (int cb = 0; cb < C / 16; ++cb) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * cb + 4 * g4);
+            f32x4 v = xr[pb][cb];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = 32 * t + 8 * q;
-                const float4 bb = *reinterpret_cast<const float4*>(b2 + c + 4 * hh);
-                float4 v = xr[pt][4 * t + q];
-                v.x += fmaf(acc[pt][t][4 * q + 0], sinv2, bb.x);
-                v.y += fmaf(acc[pt][t][4 * q + 1], sinv2, bb.y);
-                v.z += fmaf(acc[pt][t][4 * q + 2], sinv2, bb.z);
-                v.w += fmaf(acc[pt][t][4 * q + 3], sinv2, bb.w);
-                *reinterpret_cast<float4*>(xp + c) = v;
-            }
+            for (int e = 0; e < 4; ++e) v[e] += fmaf(acc[cb][pb][e], sinv2, bb[e]);
+            *reinterpret_cast<f32x4*>(xp + 16 * cb) = v;
         }
     }
     }
