@@ -25,8 +25,8 @@
 //               GELU + hi/lo split of X(k) -> G(k): 30 single-instruction "nano-steps" per register pair (split_math.h,
 //               gelu_nano), half of the pairs dealt over the MFMAs of segment 2k, the other half over those of segment
 //               2k+1.  One wave per SIMD issues both streams: about five single-issue instructions ride for free behind
-//               32 cycles of matrix work (a 32x32x16 MFMA then, a pair of 16x16x32 now), every further one costs ~5 cycles (profiles/r03_d_coissue_table_full.txt), so each MFMA
-//               gap gets at most four slots, fewer where an LDS-DMA piece or the fragment reads of the next unit already
+//               32 cycles of matrix work (a 32x32x16 MFMA then, a pair of 16x16x32 now), every further one costs ~5 cycles
+//               (profiles/r03_d_coissue_table_full.txt), so each gap behind a pair gets at most four slots, fewer where an LDS-DMA piece or the fragment reads of the next unit already
 //               sit in it (WideCfg::gap_free).
 //               The DMA pieces of segment s+2 are threaded through the units of segment s; one counted s_waitcnt vmcnt +
 //               s_barrier per segment.
