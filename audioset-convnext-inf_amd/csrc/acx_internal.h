@@ -69,6 +69,17 @@ constexpr size_t kCuLdsBytes = 160 * 1024;
 #define ACX_CLAIM_VGPR(n) asm volatile("" ::: "v" #n)
 #define ACX_CLAIM_AGPR(n) asm volatile("" ::: "a" #n)
 
+// XOR swizzle of the 16-byte chunks of a 128-byte LDS row (the S16 k-tile rows of gemm_split.hip, the W2c images of
+// mlp_fused_wide.hip): chunk c of row r sits at position c ^ acx_swz8(r).  A permutation of the plain (r >> 1) & 7 chosen for
+// the lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... -- MI355X_MICROARCH.md, LDS): with it the
+// fragment reads of BOTH MFMA shapes are conflict-free -- 32x32x16 (lane = row l & 31, two k blocks) and 16x16x32 (lane =
+// row l & 15, k block l >> 4), where the plain form is 2-way (profiles/r03_p_split_pmc_per_kernel.csv: 0.09-0.14 conflict
+// cycles per CU cycle in the first 16x16x32 build).
+__host__ __device__ constexpr int acx_swz8(int row) {
+    const int t = (row >> 1) & 7;
+    return (t & 4) | ((t & 1) << 1) | (((t >> 1) ^ (t >> 2) ^ 1) & 1);
+}
+
 // Lanes l and l + 32 -- the two channel halves of one pixel row in the 32 x 32 MFMA layouts -- trade one register each
 // (v_permlane32_swap_b32): afterwards the LOWER lane holds (its own a, the upper lane's a) in (a, b) and the UPPER lane
 // (the lower lane's b, its own b).  Epilogues use it to turn two 8-byte pieces per lane, interleaved with the partner's,

@@ -399,7 +399,7 @@ static int finalize_impl(acx_ctx* c) {
                         }
                     // W2 image of chunk k: row = out channel (128 B = 8 chunks); content chunk 2b (hi) / 2b + 1 (lo) of
                     // block b (= k block g4 of the 16x16x32 MFMA) holds hidden units 32k + 16(jj >> 2) + 4b + (jj & 3) -- the order
-                    // in which a lane's accumulators of phase 1 become its B operand of phase 2 --, at position ^ ((ch >> 1) & 7)
+                    // in which a lane's accumulators of phase 1 become its B operand of phase 2 --, at position ^ acx_swz8(ch)
                     uint16_t* w2img = st.data() + (size_t)(k == nch - 1 ? 2 * nch - 1 : 2 * k + 2) * seg;
                     for (int ch = 0; ch < C; ++ch)
                         for (int b = 0; b < 4; ++b) {
@@ -412,7 +412,7 @@ static int finalize_impl(acx_ctx* c) {
                                 std::memcpy(&hi8[jj], &hi, 2);
                                 std::memcpy(&lo8[jj], &lo, 2);
                             }
-                            const int sw = (ch >> 1) & 7;
+                            const int sw = acx_swz8(ch);
                             std::memcpy(w2img + ((size_t)ch * 128 + (size_t)((2 * b) ^ sw) * 16) / 2, hi8, 16);
                             std::memcpy(w2img + ((size_t)ch * 128 + (size_t)((2 * b + 1) ^ sw) * 16) / 2, lo8, 16);
                         }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
 #pragma unroll
     for (int i = 0; i < A_DMA; ++i) {
         const int row = A_DMA * 8 * wave + 8 * i + prow;
-        const int chunk = pchunk ^ ((row >> 1) & 7);
+        const int chunk = pchunk ^ acx_swz8(row);
         long long m = m0 + row;
         if (m >= p.M) m = p.M - 1;
         if (GATHER) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
 #pragma unroll
     for (int i = 0; i < B_DMA; ++i) {
         const int row = B_DMA * 8 * wave + 8 * i + prow;
-        const int chunk = pchunk ^ ((row >> 1) & 7);
+        const int chunk = pchunk ^ acx_swz8(row);
         b_src[i] = p.Wt + (long long)(n0 + row) * p.K * 4 + 16 * chunk;
     }
     char* a_dst = As + A_DMA * 8 * wave * kSRowBytes;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int sw = (l31 >> 1) & 7;
+    const int sw = acx_swz8(l31);
     int foff_hi[2], foff_lo[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
 // bare loops on random operands +5..10 % TFLOP/s), and a timing-only substitution in this kernel took 5-7 % off its
 // launches.  Same tiles (256 x 192 x 32, 4 x 2 waves of 64 x 96), same LDS images, same LDS-DMA schedule; what changes:
 //   * a 16x16x32 MFMA contracts the WHOLE 32-k LDS row of 16 rows: lane l reads row l & 15, block l >> 4 (hi chunk
-//     2 (l >> 4), lo chunk + 1, XOR (row >> 1) & 7 as the DMA wrote it: 16 rows x 4 blocks land in distinct banks);
+//     2 (l >> 4), lo chunk + 1, XOR acx_swz8(row) as the DMA wrote it: conflict-free for the lane groups of ds_read_b128);
 //   * a k-tile is ONE step of 3 x 4 x 6 = 72 MFMAs of 16 cycles.  It runs as two halves over the weight blocks (n blocks
 //     0-2, then 3-5) so that the fragment registers still rotate: the activation fragments (4 blocks x hi / lo) live for the
 //     whole tile and are double-buffered (A0 / A1, the loop is unrolled by two), the weight fragments of a half are re-read
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
 #pragma unroll
     for (int i = 0; i < A_DMA; ++i) {
         const int row = A_DMA * 8 * wave + 8 * i + prow;
-        const int chunk = pchunk ^ ((row >> 1) & 7);
+        const int chunk = pchunk ^ acx_swz8(row);
         long long m = m0 + row;
         if (m >= p.M) m = p.M - 1;
         if (GATHER) {
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
 #pragma unroll
     for (int i = 0; i < B_DMA; ++i) {
         const int row = B_DMA * 8 * wave + 8 * i + prow;
-        const int chunk = pchunk ^ ((row >> 1) & 7);
+        const int chunk = pchunk ^ acx_swz8(row);
         b_src[i] = p.Wt + (long long)(n0 + row) * p.K * 4 + 16 * chunk;
     }
     char* a_dst = As + A_DMA * 8 * wave * kSRowBytes;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int sw = (l15 >> 1) & 7;
+    const int sw = acx_swz8(l15);
     const int foff_hi = l15 * kSRowBytes + (((2 * g4) ^ sw) << 4);
     const int foff_lo = l15 * kSRowBytes + (((2 * g4 + 1) ^ sw) << 4);
     const int a_frag_off = wm * 64 * kSRowBytes;

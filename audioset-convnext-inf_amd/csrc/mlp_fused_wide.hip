@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     // l15 of a 16-row block, the 8 k of block g4 of the 32-k step:
     //   W1 image: row = hidden unit (4 C bytes = C/4 chunks of 16 B), 16-row block hb; chunk p = 8 s32 + 2 g4 + pl at position
     //             p ^ l15 (pl = 0 hi halves, 1 lo halves; the XOR touches the low 4 bits only: C % 64 == 0)
-    //   W2 image: row = out channel (128 B = 8 chunks), block cb rows 16 cb + l15, chunk 2 g4 + pl at position ^ ((l15 >> 1) & 7)
+    //   W2 image: row = out channel (128 B = 8 chunks), block cb rows 16 cb + l15, chunk 2 g4 + pl at position ^ acx_swz8(l15)
     static_assert(C % 64 == 0, "W1 image swizzle");
     int w1off[2][2], w2off[2];
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) w1off[q][pl] = l15 * (4 * C) + (((8 * q + 2 * g4 + pl) ^ l15) << 4);
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) w2off[pl] = l15 * 128 + (((2 * g4 + pl) ^ ((l15 >> 1) & 7)) << 4);
+    for (int pl = 0; pl < 2; ++pl) w2off[pl] = l15 * 128 + (((2 * g4 + pl) ^ acx_swz8(l15)) << 4);
     const GeluK2 gk = gelu_k2(sinv1, hscale);
 
 #define ACX_H8(v_) __builtin_bit_cast(h8, v_)

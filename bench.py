@@ -411,7 +411,7 @@ def main():
                           "algorithmic_GBs": nbytes / (ms * 1e-3) / 1e9}
         line["kernels"] = kernels
         # the matrix kernels by NAME: the event classes pw1 and pw2 are launches of one kernel
-        gemm_name = {"fp32": "gemm_f32_kernel", "bf16": "gemm_bf16_kernel", "bf16a": "gemm_bf16_kernel", "fp32_split": "gemm_split_kernel"}[args.precision]
+        gemm_name = {"fp32": "gemm_f32_kernel", "bf16": "gemm_bf16_kernel", "bf16a": "gemm_bf16_kernel", "fp32_split": "gemm_split16_kernel"}[args.precision]
         fused_name = {"fp32": "mlp_fused_kernel", "bf16": "mlp_fused_bf16_kernel", "bf16a": "mlp_fused_bf16_kernel", "fp32_split": "mlp_fused_split_kernel"}[args.precision]
         groups = {gemm_name + " (pwconv1+GELU and pwconv2+residual launches, two-GEMM stages)": ("pw1", "pw2"),
                   fused_name + " (LN+pwconv1+GELU+pwconv2+residual in one launch)": ("mlp_fused",),

@@ -22,6 +22,9 @@ def cls(name):
                    ("rowstats", "rowstats"), ("pool_head", "poolhead"), ("nhwc_to_nchw", "transpose")):
         if key in name:
             return c
+    if "gemm_split16_kernel" in name:          # <EPI, GATHER>
+        t = name.split("<")[1].split(">")[0].replace(" ", "").split(",")
+        return {"1": "pw1", "2": "pw2"}.get(t[0], "downsample")
     if "gemm_f32_kernel" in name or "gemm_split_kernel" in name or "gemm_bf16_kernel" in name:
         t = name.split("<")[1].split(">")[0].replace(" ", "").split(",")
         return {"1": "pw1", "2": "pw2"}.get(t[4], "downsample")
