@@ -24,27 +24,132 @@ def move_data_to_device(x, device):
     return t.to(device, non_blocking=True)
 
 
+class _Stager(object):
+    """Waveform batches -> device through three pinned host buffers.  `to_pinned` runs in the reader thread (a chunked,
+    multi-threaded copy: numpy releases the GIL), `to_device` in the caller: an asynchronous copy on its own stream, beside
+    the model's work on the previous batch.  int16 batches (data_generator.evaluate_batches(device_cast=True)) cross PCIe as
+    they are and become float32 on the GPU by the arithmetic of utilities.int16_to_float32 (/32767 in double precision,
+    one rounding to float32); float32 batches are copied as they are.  A buffer is rewritten three batches later, after
+    forward() has fetched the outputs of the batch that used it."""
+    kCopyThreads = 4
+
+    def __init__(self, device):
+        self.device = device
+        self.pinned = [None, None, None]
+        self.turn = 0
+        self.copy_stream = None
+        self.pool = None
+
+    def staged(self, x):
+        x = np.asarray(x)
+        return self.device.type == "cuda" and x.dtype in (np.int16, np.float32) and x.ndim == 2
+
+    def to_pinned(self, x):
+        x = np.asarray(x)
+        n = x.size
+        buf = self.pinned[self.turn]
+        want = torch.int16 if x.dtype == np.int16 else torch.float32
+        if buf is None or buf.dtype != want or buf.numel() < n:
+            buf = torch.empty(n, dtype=want).pin_memory()
+            self.pinned[self.turn] = buf
+        self.turn = (self.turn + 1) % 3
+        host = buf[:n].view(x.shape)
+        dst = host.numpy()
+        if self.pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(self.kCopyThreads)
+        rows = x.shape[0]
+        step = (rows + self.kCopyThreads - 1) // self.kCopyThreads
+        list(self.pool.map(lambda r0: np.copyto(dst[r0:r0 + step], x[r0:r0 + step]), range(0, rows, step)))
+        return host
+
+    def to_device(self, host):
+        if self.copy_stream is None:
+            self.copy_stream = torch.cuda.Stream(self.device)
+        compute = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.copy_stream):
+            dev = host.to(self.device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        compute.wait_event(ready)
+        dev.record_stream(compute)
+        if dev.dtype == torch.int16:
+            dev = (dev.to(torch.float64) / 32767.0).to(torch.float32)
+        return dev
+
+    def plain(self, x):
+        x = np.asarray(x)
+        if x.dtype == np.int16:
+            return torch.from_numpy((x / 32767.0).astype(np.float32)).to(self.device)
+        return move_data_to_device(x, self.device)
+
+
+def _ahead(generator, prepare, depth=1):
+    """Runs `generator` (and `prepare` on each item) in a background thread, `depth` batches ahead: reading the clips
+    (memory-mapped shards), any host-side conversion and the copy into pinned memory overlap the GPU's work on the previous
+    batch.  Exceptions re-raise in the consumer."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    done = object()
+
+    def work():
+        try:
+            for item in generator:
+                q.put((item, prepare(item)))
+            q.put(done)
+        except BaseException as e:      # noqa: B902 -- handed to the consumer
+            q.put(e)
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    while True:
+        item = q.get()
+        if item is done:
+            break
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+    t.join()
+
+
 def forward(model, generator, return_input=False, return_target=False):
-    """Forward data to a model in mini-batches (pytorch_utils.py:63-137)."""
+    """Forward data to a model in mini-batches (pytorch_utils.py:63-137).  Same results in the same order; the batches are
+    read and staged into pinned memory one ahead in a background thread, copied to the device on a side stream, and the
+    outputs of batch i are fetched only after batch i + 1 has been handed to the GPU: host work, PCIe and the model overlap."""
     output = {}
     device = next(model.parameters()).device
     model.eval()
+    stage = _Stager(device)
 
     def append(key, value):
         output.setdefault(key, []).append(value)
 
-    for batch in generator:
-        batch_x = move_data_to_device(batch["waveform"], device)
-        with torch.no_grad():
-            batch_out = model(batch_x)
+    def collect(pending):
+        batch, batch_out = pending
         append("clipwise_output", batch_out["clipwise_output"].data.cpu().numpy())
         for key in ("segmentwise_output", "framewise_output"):
             if key in batch_out:
                 append(key, batch_out[key].data.cpu().numpy())
         if return_input:
-            append("waveform", batch["waveform"])
+            w = batch["waveform"]
+            append("waveform", w if np.asarray(w).dtype != np.int16 else (np.asarray(w) / 32767.0).astype(np.float32))
         if return_target and "target" in batch:
             append("target", batch["target"])
+
+    def prepare(batch):                     # reader thread
+        return stage.to_pinned(batch["waveform"]) if stage.staged(batch["waveform"]) else None
+
+    pending = None
+    for batch, host in _ahead(generator, prepare):
+        batch_x = stage.to_device(host) if host is not None else stage.plain(batch["waveform"])
+        with torch.no_grad():
+            batch_out = model(batch_x)
+        if pending is not None:
+            collect(pending)                # synchronises with the PREVIOUS batch only
+        pending = (batch, batch_out)
+    if pending is not None:
+        collect(pending)
     return {k: np.concatenate(v, axis=0) for k, v in output.items()}
 
 
@@ -74,7 +179,7 @@ def evaluate_sharded(model, shard, batch_size=256):
     from ..utils.data_generator import evaluate_batches
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
-    out = forward(model, evaluate_batches(shard, batch_size, rank, world), return_target=True)
+    out = forward(model, evaluate_batches(shard, batch_size, rank, world, device_cast=True), return_target=True)
     scores, target = out.get("clipwise_output"), out.get("target")
     if world > 1:
         device = next(model.parameters()).device

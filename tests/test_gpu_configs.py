@@ -114,8 +114,15 @@ def test_eval_sweep_2048_clips(model, synth_sd):
     t0 = time.perf_counter()
     out = ev.forward(model, evaluate_batches(shard, batch_size=256), return_target=True)
     dt = time.perf_counter() - t0
-    print("eval sweep: %d clips in %.2f s = %.0f clips/s including int16 -> float32 and H2D" % (n, dt, n / dt))
+    print("eval sweep: %d clips in %.2f s = %.0f clips/s including int16 -> float32 on the host and H2D" % (n, dt, n / dt))
     assert out["clipwise_output"].shape == (n, 527) and np.isfinite(out["clipwise_output"]).all()
+    # the same sweep with the clips crossing PCIe as int16 and /32767 done on the GPU (what evaluate_sharded does): same bits
+    ev.forward(model, evaluate_batches(shard, batch_size=256, device_cast=True))       # pinned buffers allocated
+    t0 = time.perf_counter()
+    fast = ev.forward(model, evaluate_batches(shard, batch_size=256, device_cast=True), return_target=True)
+    dt = time.perf_counter() - t0
+    print("eval sweep, int16 over PCIe + cast on the GPU: %d clips in %.2f s = %.0f clips/s" % (n, dt, n / dt))
+    assert np.array_equal(fast["clipwise_output"], out["clipwise_output"]) and np.array_equal(fast["target"], out["target"])
     out64 = ev.forward(model, evaluate_batches(shard, batch_size=64))
     assert np.array_equal(out64["clipwise_output"], out["clipwise_output"])
     pick = [0, 255, 256, 1000, 1023, 1500, 2046, 2047]
