@@ -26,7 +26,7 @@ def extract(model, waveforms, what="logits", max_batch=64):
         for s in range(0, len(idx), max_batch):
             chunk = idx[s:s + max_batch]
             batch = torch.stack([torch.as_tensor(waveforms[i], dtype=torch.float32) for i in chunk]).to(device)
-            res = fn(batch)
+            res = fn(batch).cpu()            # one device -> host copy per chunk, not one per clip
             for j, i in enumerate(chunk):
-                out[i] = res[j].cpu()
+                out[i] = res[j].clone()
     return out
