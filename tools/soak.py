@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audioset_convnext_inf_amd import synth
 from audioset_convnext_inf_amd.pytorch.convnext import convnext_tiny
 sd = synth.synth_state_dict(0)
-for prec in ("fp32_split", "bf16", "fp32"):
+for prec in ("fp32_split", "bf16", "bf16a", "fp32"):
     m = convnext_tiny(after_stem_dim=[252, 56]); m.load_state_dict(sd); m = m.to("cuda").eval().set_precision(prec)
     for B, L in ((64, 320000), (5, 52000), (32, 160000)):
         wav = synth.synth_waveforms(B, L, seed=B).cuda()
