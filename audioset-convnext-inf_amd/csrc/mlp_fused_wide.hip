@@ -64,6 +64,9 @@ __device__ unsigned long long acx_fw_stamps[2048 * 4 * 8];
 // Measured for C = 96 (stage 0), where a segment is only 18 MFMAs per pixel tile against the fixed cost of a segment
 // (three LDS-DMA issues, the barrier) and 36 GELU micro-steps: PT = 2 is correct (parity suite green) but runs 647 us per
 // block against 595 for the 8-wave mlp_fused_split_kernel<96>, which therefore keeps stage 0.
+#ifndef ACX_NANO_HEAD
+#define ACX_NANO_HEAD 30
+#endif
 template <int C, int PT>
 struct WideCfg {
     static constexpr int kWaves = 4;
@@ -93,11 +96,14 @@ struct WideCfg {
         const int f0 = (u % kDmaStride == 0) ? 1 : 4;
         return PT * (cum_free_units(u) + (pos == 0 ? f0 : (pos == 1 ? f0 + 4 : f0 + 5)));
     }
+    // the first kNanoHead nano-steps of a segment are issued at its top, right behind the reads of its first three fragment
+    // pairs -- under an LDS latency nothing else could hide -- the rest is dealt over the gaps
+    static constexpr int kNanoHead = ACX_NANO_HEAD;
     __host__ __device__ static constexpr int nano_end(int m) {      // nano-steps issued once the gap behind MFMA m is done
         constexpr int tot = PT * cum_free_units(kUnits);
-        return (kNano * cum_free(m) + tot / 2) / tot;
+        return kNanoHead + ((kNano - kNanoHead) * cum_free(m) + tot / 2) / tot;
     }
-    __host__ __device__ static constexpr int nano_begin(int m) { return m == 0 ? 0 : nano_end(m - 1); }
+    __host__ __device__ static constexpr int nano_begin(int m) { return m == 0 ? kNanoHead : nano_end(m - 1); }
     // W1 rows are 4 C bytes: the XOR that spreads 16 consecutive rows over the LDS banks (api.hip packs the image with it)
     __device__ static int swz1(int row) { return (C % 64 == 0) ? (row & 15) : ((row >> 1) & 7); }
 };
@@ -136,9 +142,14 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     // (issued from inline asm: next to the builtin form hipcc waits lgkmcnt(0) / vmcnt(0) wherever an LDS read follows, which
     // defeats the two-unit look-ahead of the fragment reads; the counted waits at the segment ends are this file's own)
     const unsigned smem_a = acx_lds_addr(smem);
+    // pieces 8 g .. 8 g + 7 of a segment share one M0 / base pair, set at the group's first piece and centred on its fifth
+    const char* wbase = wstream;
 #define ACX_WDMA(seg_, piece_, grp_)                                                                             \
-        acx_glds16_own_m0(wstream + (long long)(seg_) * Cfg::kSegBytes + dma_lane + (piece_) * 1024,             \
-                          __builtin_amdgcn_readfirstlane(smem_a + (grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_)) * 1024));
+        {   if ((piece_) % 8 == 0) {                                                                             \
+                wbase = wstream + (long long)(seg_) * Cfg::kSegBytes + dma_lane + ((piece_) + 4) * 1024;         \
+                acx_set_m0(__builtin_amdgcn_readfirstlane(smem_a + (grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_) + 4) * 1024)); \
+            }                                                                                                    \
+            acx_glds16_run(wbase, (piece_) % 8); }
     // segments 0 and 1 are requested before anything else; segment s + 2 follows during segment s
 #pragma unroll
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(0, p, 0)
@@ -254,37 +265,39 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     // 2 e, 2 e + 1 of X block 2 pb + hb: hidden units 16 hb + 4 g4 + 2 e, + 1 of pixel block pb
 #define ACX_NANO_RANGE(half_, from_, to_)                                                                       \
         _Pragma("unroll") for (int ng_ = (from_); ng_ < (to_); ++ng_) {                                         \
-            const int mt_ = ng_ / (4 * kGeluNano), pr_ = 4 * (half_) + (ng_ % (4 * kGeluNano)) / kGeluNano, st_ = ng_ % kGeluNano; \
-            if (st_ == 0) { gsA.ax = Xv[(2 * pr_) >> 2][(2 * pr_) & 3]; gsA.ay = Xv[(2 * pr_) >> 2][((2 * pr_) & 3) + 1]; gelu_nano<0>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]); } \
-            else if (st_ == 1) gelu_nano<1>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 2) gelu_nano<2>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 3) gelu_nano<3>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 4) gelu_nano<4>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 5) gelu_nano<5>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 6) gelu_nano<6>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 7) gelu_nano<7>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 8) gelu_nano<8>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 9) gelu_nano<9>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 10) gelu_nano<10>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 11) gelu_nano<11>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 12) gelu_nano<12>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 13) gelu_nano<13>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 14) gelu_nano<14>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 15) gelu_nano<15>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 16) gelu_nano<16>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 17) gelu_nano<17>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 18) gelu_nano<18>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 19) gelu_nano<19>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 20) gelu_nano<20>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 21) gelu_nano<21>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 22) gelu_nano<22>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 23) gelu_nano<23>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 24) gelu_nano<24>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 25) gelu_nano<25>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 26) gelu_nano<26>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 27) gelu_nano<27>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 28) gelu_nano<28>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 29) gelu_nano<29>(gsA, gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            /* two register pairs in flight, their instructions alternating: consecutive nano-steps never depend on each other */ \
+            const int j_ = ng_ % (2 * kGeluNano), w_ = j_ & 1, mt_ = 0;                                         \
+            const int pr_ = 4 * (half_) + 2 * (ng_ / (2 * kGeluNano)) + w_, st_ = j_ >> 1;                      \
+            if (st_ == 0) { gsv[w_].ax = Xv[(2 * pr_) >> 2][(2 * pr_) & 3]; gsv[w_].ay = Xv[(2 * pr_) >> 2][((2 * pr_) & 3) + 1]; gelu_nano<0>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]); } \
+            else if (st_ == 1) gelu_nano<1>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 2) gelu_nano<2>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 3) gelu_nano<3>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 4) gelu_nano<4>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 5) gelu_nano<5>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 6) gelu_nano<6>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 7) gelu_nano<7>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 8) gelu_nano<8>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 9) gelu_nano<9>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 10) gelu_nano<10>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 11) gelu_nano<11>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 12) gelu_nano<12>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 13) gelu_nano<13>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 14) gelu_nano<14>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 15) gelu_nano<15>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 16) gelu_nano<16>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 17) gelu_nano<17>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 18) gelu_nano<18>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 19) gelu_nano<19>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 20) gelu_nano<20>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 21) gelu_nano<21>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 22) gelu_nano<22>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 23) gelu_nano<23>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 24) gelu_nano<24>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 25) gelu_nano<25>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 26) gelu_nano<26>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 27) gelu_nano<27>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 28) gelu_nano<28>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            else if (st_ == 29) gelu_nano<29>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
         }
 #define ACX_TOUCH2(h_, l_) asm volatile("" :: "v"(h_), "v"(l_));
 #define ACX_BIAS_INIT(j_)                                                                                       \
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     f32x4 Xn[4], Xv[4];           // X^T blocks 2 pb + hb (16 hidden x 16 pixels each): Xn being accumulated by phase 1; Xv: the previous chunk's, input of the GELU
     f32x4 gh[2], gl[2];           // G(k - 1): B operand of phase 2 per pixel block, hi / lo halves
     unsigned uh[PT][8], ul[PT][8];
-    GeluState2 gsA;
+    GeluState2 gsv[2];
 
     // one phase-1 segment: X = b1 + W1c . LN(y)^T for chunk k_, image in ring slot grp_, requesting segment seg_ + 2
     auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
@@ -326,6 +339,9 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         static_assert(Cfg::kSteps % 3 == 0, "the unit loop is unrolled by three");
         f32x4 f0h = ACX_W1_RD(base, 0, 0), f0l = ACX_W1_RD(base, 0, 1), f1h = ACX_W1_RD(base, 1, 0), f1l = ACX_W1_RD(base, 1, 1),
               f2h = ACX_W1_RD(base, 2, 0), f2l = ACX_W1_RD(base, 2, 1);
+        ACX_FENCE
+        if constexpr (HV) { ACX_NANO_RANGE(1, 0, Cfg::kNanoHead) }
+        ACX_FENCE
         // unit s_: MFMAs on the current set; in the gap behind its last MFMA the (counted) wait for the NEXT unit's set, then
         // the reads of unit s_ + 3 into the set just freed
 #define ACX_P1_UNIT(s_, ch_, cl_, th_, tl_)                                                                     \
@@ -356,6 +372,9 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         static_assert(Cfg::kUnits % 3 == 0, "the unit loop is unrolled by three");
         f32x4 f0h = ACX_W2_RD(base, 0, 0), f0l = ACX_W2_RD(base, 0, 1), f1h = ACX_W2_RD(base, 1, 0), f1l = ACX_W2_RD(base, 1, 1),
               f2h = ACX_W2_RD(base, 2, 0), f2l = ACX_W2_RD(base, 2, 1);
+        ACX_FENCE
+        if constexpr (HV) { ACX_NANO_RANGE(0, 0, Cfg::kNanoHead) }
+        ACX_FENCE
 #define ACX_P2_UNIT(i_, ch_, cl_, th_, tl_)                                                                     \
             ACX_FENCE                                                                                           \
             ACX_P2_MFMA(i_, ch_, cl_)                                                                           \

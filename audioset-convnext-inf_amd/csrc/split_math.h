@@ -115,6 +115,25 @@ __device__ __forceinline__ void acx_glds16(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void acx_glds16_own_m0(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// A RUN of pieces that are 1 KB apart in the stream AND in the LDS (a wave's pieces of one segment): the immediate offset of
+// global_load_lds applies to both addresses (verified on the part: offset:1024 moves source and destination by 1 KB), so one
+// M0 write + one 64-bit base serve up to eight pieces (13-bit signed immediate: -4096 .. 3072) and a piece is ONE instruction
+// instead of five (v_lshl_add_u64, s_add, s_mov m0, s_nop, the load) -- in a loop where every issued instruction of the single
+// wave per SIMD costs ~3-4 exposed cycles (profiles/r03_r_wide384_cycles.txt).  Same M0 contract as acx_glds16_own_m0.
+__device__ __forceinline__ void acx_set_m0(unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(lds_dst) : "memory");
+}
+// piece j (0..7) of the run whose base points at piece 4: offset (j - 4) KB.  j must fold to a constant (unrolled loops): the
+// immediate is part of the instruction.
+__device__ __forceinline__ void acx_glds16_run(const void* gbase, int j) {
+#define ACX_GLDS_CASE(J_) case J_: asm volatile("global_load_lds_dwordx4 %0, off offset:%1" :: "v"(gbase), "n"(((J_) - 4) * 1024) : "memory"); break;
+    switch (j) {
+        ACX_GLDS_CASE(0) ACX_GLDS_CASE(1) ACX_GLDS_CASE(2) ACX_GLDS_CASE(3)
+        ACX_GLDS_CASE(4) ACX_GLDS_CASE(5) ACX_GLDS_CASE(6) ACX_GLDS_CASE(7)
+        default: __builtin_unreachable();
+    }
+#undef ACX_GLDS_CASE
+}
 // on ? a : b without a select the compiler could turn into a branch (a branch inside a hand-placed loop body splits it into
 // basic blocks and lets code sink out of its MFMA gaps)
 __device__ __forceinline__ unsigned acx_pick(bool on, unsigned a, unsigned b) {

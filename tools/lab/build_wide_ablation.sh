@@ -15,12 +15,20 @@ variant() {   # name, sed expressions...
 }
 variant full
 EXTRA=-DACX_FW_STAMPS variant stamps
-variant nogelu 's/^(\s+)ACX_FENCE if constexpr \(HV_\) \{ ACX_MICRO_RANGE.*$/\1ACX_FENCE/'
+variant nogelu 's/^(\s+)ACX_FENCE if constexpr \(HV_\) \{ ACX_NANO_RANGE.*$/\1ACX_FENCE/'
 variant nodma 's/^        acx_glds16_own_m0\(wstream/        if (0) acx_glds16_own_m0(wstream/'
 variant nobarrier 's/^        __builtin_amdgcn_s_barrier\(\);  /  /'
-variant nodsread 's/^#define ACX_W1_RD\(base_, s_, pl_\).*/#define ACX_W1_RD(base_, s_, pl_) (acth[0][(s_) % 4])/; s/^#define ACX_W2_RD\(base_, i_, pl_\).*/#define ACX_W2_RD(base_, i_, pl_) (actl[0][(i_) % 4])/'
-variant nomfma 's/^(\s+)(Xn\[pt_\]|acc\[pt_\]\[\(i_\) >> 1\]) = __builtin_amdgcn_mfma_f32_32x32x16_f16\((ACX_H8\([a-z_]+\)), (ACX_H8\([^)]*\)\)?), .*$/\1asm volatile("" :: "v"(\3), "v"(\4)); \\/'
-EXTRA=-DACX_FW_STAMPS variant stamps_nomfma 's/^(\s+)(Xn\[pt_\]|acc\[pt_\]\[\(i_\) >> 1\]) = __builtin_amdgcn_mfma_f32_32x32x16_f16\((ACX_H8\([a-z_]+\)), (ACX_H8\([^)]*\)\)?), .*$/\1asm volatile("" :: "v"(\3), "v"(\4)); \\/'
+variant nodsread 's/^#define ACX_W1_RD\(base_, u_, pl_\).*/#define ACX_W1_RD(base_, u_, pl_) (acth[0][(u_) % 4])/; s/^#define ACX_W2_RD\(base_, i_, pl_\).*/#define ACX_W2_RD(base_, i_, pl_) (actl[0][(i_) % 4])/'
+variant nomfma 's/^#define ACX_M16\(a_, b_, c_\).*/#define ACX_M16(a_, b_, c_) asm volatile("" :: "v"(a_), "v"(b_));/'
+EXTRA=-DACX_FW_STAMPS variant stamps_nomfma 's/^#define ACX_M16\(a_, b_, c_\).*/#define ACX_M16(a_, b_, c_) asm volatile("" :: "v"(a_), "v"(b_));/'
+NOGELU='s/^(\s+)ACX_FENCE if constexpr \(HV_\) \{ ACX_NANO_RANGE.*$/\1ACX_FENCE/; s/^        if constexpr \(HV\) \{ ACX_NANO_RANGE\([01], 0, Cfg::kNanoHead\) \}$/ /'
+NODS='s/^#define ACX_W1_RD\(base_, u_, pl_\).*/#define ACX_W1_RD(base_, u_, pl_) (acth[0][(u_) % 4])/; s/^#define ACX_W2_RD\(base_, i_, pl_\).*/#define ACX_W2_RD(base_, i_, pl_) (actl[0][(i_) % 4])/'
+NODMA='s/^        acx_glds16_own_m0\(wstream/        if (0) acx_glds16_own_m0(wstream/'
+EXTRA=-DACX_FW_STAMPS variant st_nogelu "$NOGELU"
+EXTRA=-DACX_FW_STAMPS variant st_nodsread "$NODS"
+EXTRA=-DACX_FW_STAMPS variant st_nodma "$NODMA"
+EXTRA=-DACX_FW_STAMPS variant st_nogelu_nodsread "$NOGELU" "$NODS"
+EXTRA=-DACX_FW_STAMPS variant st_nogelu_nodsread_nodma "$NOGELU" "$NODS" "$NODMA"
 wait
 for v in nogelu nodma nobarrier nodsread nomfma; do echo "$v: $(diff $O/src/ablw${C}_full.hip $O/src/ablw${C}_$v.hip | grep -c '^[<>]') changed lines"; done
 ls $O | grep ablw$C
