@@ -64,9 +64,6 @@ __device__ unsigned long long acx_fw_stamps[2048 * 4 * 8];
 // Measured for C = 96 (stage 0), where a segment is only 18 MFMAs per pixel tile against the fixed cost of a segment
 // (three LDS-DMA issues, the barrier) and 36 GELU micro-steps: PT = 2 is correct (parity suite green) but runs 647 us per
 // block against 595 for the 8-wave mlp_fused_split_kernel<96>, which therefore keeps stage 0.
-#ifndef ACX_NANO_HEAD
-#define ACX_NANO_HEAD 30
-#endif
 template <int C, int PT>
 struct WideCfg {
     static constexpr int kWaves = 4;
@@ -84,24 +81,28 @@ struct WideCfg {
     // GELU nano-steps (single instructions, split_math.h) a segment carries: half of a pixel tile's 8 register pairs
     static constexpr int kNano = 4 * kGeluNano * PT;
     static_assert(C % 32 == 0 && kSteps == kUnits && kUnits % kPieces == 0, "unit / piece bookkeeping");
-    // Issue budget of the gap BEHIND MFMA m of a segment (unit m / 3 / PT, position m % 3 for PT = 1).  A gap hides about
-    // five single-issue instructions (profiles/r03_a_coissue_table.txt); the fixed tenants are the LDS-DMA piece (s_mov m0,
-    // s_nop, the load: behind the FIRST MFMA of every kDmaStride-th unit) and the counted wait + two fragment reads (behind
-    // the LAST MFMA of every unit).  What is left of four slots per gap is dealt to the GELU in proportion.
+    // Issue budget of the gap BEHIND MFMA m of a segment (unit m / 6, position m % 6: the three terms x the two pixel blocks).
+    // Behind a 16x16x32 MFMA (16 matrix cycles) TWO single-issue instructions are free and every further one costs ~5 cycles;
+    // fillers behind the second MFMA of a back-to-back pair do not use the first one's shadow (tools/lab/coissue2.hip,
+    // profiles/r03_s_coissue_16x16.txt: pair + 4 fillers 44.0 cycles per 32 matrix cycles, 2 behind each MFMA 34.3).  So every
+    // filler of the loop has a gap of its own: position 0 the LDS-DMA piece of every kDmaStride-th unit (one instruction),
+    // position 1 the read of the lo fragment three units ahead (its register is dead after the first term), position 4 the
+    // counted wait for the next unit's fragments, position 5 the read of the hi fragment; what is left -- 2 / 1 / 2 / 2 / 1 / 1 --
+    // is dealt to the GELU in proportion.
     // (closed forms, no loops: the arguments become constants only after the unit loops are unrolled, and everything derived
     // from them -- register indices above all -- must fold then)
-    __host__ __device__ static constexpr int cum_free_units(int u) { return 9 * u - 3 * ((u + kDmaStride - 1) / kDmaStride); }   // gaps of units [0, u)
-    __host__ __device__ static constexpr int cum_free(int m) {       // free slots of gaps [0, m]
-        const int g = m / PT, u = g / 3, pos = g % 3;
-        const int f0 = (u % kDmaStride == 0) ? 1 : 4;
-        return PT * (cum_free_units(u) + (pos == 0 ? f0 : (pos == 1 ? f0 + 4 : f0 + 5)));
+    __host__ __device__ static constexpr int cum_cap_units(int u) { return 9 * u - ((u + kDmaStride - 1) / kDmaStride); }   // gaps of units [0, u)
+    __host__ __device__ static constexpr int cum_cap(int m) {       // free slots of gaps [0, m]
+        const int u = m / 6, pos = m % 6;
+        const int c0 = (u % kDmaStride == 0) ? 1 : 2;
+        return cum_cap_units(u) + (pos == 0 ? c0 : pos == 1 ? c0 + 1 : pos == 2 ? c0 + 3 : pos == 3 ? c0 + 5 : pos == 4 ? c0 + 6 : c0 + 7);
     }
-    // the first kNanoHead nano-steps of a segment are issued at its top, right behind the reads of its first three fragment
-    // pairs -- under an LDS latency nothing else could hide -- the rest is dealt over the gaps
-    static constexpr int kNanoHead = ACX_NANO_HEAD;
+    // what does not fit the gaps (C = 192: 120 nano-steps per segment, 102 slots) is issued at the top of the segment, right
+    // behind the reads of its first three fragment pairs
+    static constexpr int kCapTotal = cum_cap_units(kUnits);
+    static constexpr int kNanoHead = kNano > kCapTotal ? ((kNano - kCapTotal + 1) / 2) * 2 : 0;
     __host__ __device__ static constexpr int nano_end(int m) {      // nano-steps issued once the gap behind MFMA m is done
-        constexpr int tot = PT * cum_free_units(kUnits);
-        return kNanoHead + ((kNano - kNanoHead) * cum_free(m) + tot / 2) / tot;
+        return kNanoHead + ((kNano - kNanoHead) * cum_cap(m) + kCapTotal / 2) / kCapTotal;
     }
     __host__ __device__ static constexpr int nano_begin(int m) { return m == 0 ? kNanoHead : nano_end(m - 1); }
     // W1 rows are 4 C bytes: the XOR that spreads 16 consecutive rows over the LDS banks (api.hip packs the image with it)
@@ -230,36 +231,13 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     // phase-1 unit u_ = (32-channel step s32 = u_ >> 1, hidden block hb = u_ & 1): the bits of the chunk index above the XORed
     // four = s32 >> 1 -> + 256 B each
 #define ACX_W1_RD(base_, u_, pl_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) & 1) * (16 * 4 * C) + ((u_) >> 2) * 256 + w1off[((u_) >> 1) & 1][pl_]))
-    // MFMA slot m_ of a segment -- a PAIR of 16x16x32 MFMAs, one per pixel block, 2 x 16 cycles -- is followed (behind a
-    // scheduling fence) by its share of the GELU nano-steps the segment carries (WideCfg::nano_begin / nano_end)
-#define ACX_AFTER_MFMA(HV_, half_, m_)                                                                          \
+    // MFMA m_ of a segment is followed (behind a scheduling fence) by its share of the GELU nano-steps the segment carries
+    // (WideCfg::nano_begin / nano_end: at most two, fewer where a tenant sits in the gap)
+#define ACX_NANO_AT(HV_, half_, m_)                                                                             \
         ACX_FENCE if constexpr (HV_) { ACX_NANO_RANGE(half_, Cfg::nano_begin(m_), Cfg::nano_end(m_)) } ACX_FENCE
 #define ACX_M16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ACX_H8(a_), ACX_H8(b_), c_, 0, 0, 0);
-    // the three terms of a unit, each over the two pixel blocks (independent accumulators back to back); X block index = 2 pb + hb
-#define ACX_P1_MFMA(u_, ah_, al_)                                                                               \
-        ACX_M16(al_, acth[0][(u_) >> 1], Xn[(u_) & 1])                                                          \
-        if ((u_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (u_) / Cfg::kDmaStride, g2) }              \
-        ACX_M16(al_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                    \
-        ACX_AFTER_MFMA(HV, 1, 3 * (u_) + 0)                                                                     \
-        ACX_M16(ah_, actl[0][(u_) >> 1], Xn[(u_) & 1])                                                          \
-        ACX_M16(ah_, actl[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                    \
-        ACX_AFTER_MFMA(HV, 1, 3 * (u_) + 1)                                                                     \
-        ACX_M16(ah_, acth[0][(u_) >> 1], Xn[(u_) & 1])                                                          \
-        ACX_M16(ah_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                    \
-        ACX_AFTER_MFMA(HV, 1, 3 * (u_) + 2)
     // phase-2 unit i_ = block cb of 16 out channels; K = the chunk's 32 hidden units in ONE step
 #define ACX_W2_RD(base_, i_, pl_) (*reinterpret_cast<const f32x4*>((base_) + (i_) * (16 * 128) + w2off[pl_]))
-#define ACX_P2_MFMA(i_, ah_, al_)                                                                               \
-        ACX_M16(al_, gh[0], acc[i_][0])                                                                         \
-        if ((i_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (i_) / Cfg::kDmaStride, g2) }              \
-        ACX_M16(al_, gh[1], acc[i_][1])                                                                         \
-        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 0)                                                                     \
-        ACX_M16(ah_, gl[0], acc[i_][0])                                                                         \
-        ACX_M16(ah_, gl[1], acc[i_][1])                                                                         \
-        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 1)                                                                     \
-        ACX_M16(ah_, gh[0], acc[i_][0])                                                                         \
-        ACX_M16(ah_, gh[1], acc[i_][1])                                                                         \
-        ACX_AFTER_MFMA(HV, 0, 3 * (i_) + 2)
     // nano-steps [from, to) of the kNano that segment half half_ carries: step ng_ is instruction ng_ % 30 of register pair
     // 4 half_ + ng_ / 30 (split_math.h, gelu_nano): pair after pair, in order.  Pair pr = 4 pb + 2 hb + e covers registers
     // 2 e, 2 e + 1 of X block 2 pb + hb: hidden units 16 hb + 4 g4 + 2 e, + 1 of pixel block pb
@@ -342,13 +320,27 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         ACX_FENCE
         if constexpr (HV) { ACX_NANO_RANGE(1, 0, Cfg::kNanoHead) }
         ACX_FENCE
-        // unit s_: MFMAs on the current set; in the gap behind its last MFMA the (counted) wait for the NEXT unit's set, then
-        // the reads of unit s_ + 3 into the set just freed
-#define ACX_P1_UNIT(s_, ch_, cl_, th_, tl_)                                                                     \
+        // unit u_ = (s32 = u_ >> 1, hb = u_ & 1), fragments (ch_, cl_); X block index = 2 pb + hb.  Terms: lo x hi, hi x lo, hi x hi,
+        // each over the two pixel blocks.  Every filler has its own gap (WideCfg): the lo register is dead after the first
+        // term -- the lo fragment of unit u_ + 3 is read into it there; the hi register after the last MFMA.
+#define ACX_P1_UNIT(u_, ch_, cl_, th_, tl_)                                                                     \
             ACX_FENCE                                                                                           \
-            ACX_P1_MFMA(s_, ch_, cl_)                                                                           \
-            if ((s_) + 1 < Cfg::kSteps) ACX_TOUCH2(th_, tl_)                                                    \
-            if ((s_) + 3 < Cfg::kSteps) { ch_ = ACX_W1_RD(base, (s_) + 3, 0); cl_ = ACX_W1_RD(base, (s_) + 3, 1); } \
+            ACX_M16(cl_, acth[0][(u_) >> 1], Xn[(u_) & 1])                                                      \
+            if ((u_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (u_) / Cfg::kDmaStride, g2) }          \
+            ACX_NANO_AT(HV, 1, 6 * (u_) + 0)                                                                    \
+            ACX_M16(cl_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                \
+            if ((u_) + 3 < Cfg::kSteps) cl_ = ACX_W1_RD(base, (u_) + 3, 1);                                     \
+            ACX_NANO_AT(HV, 1, 6 * (u_) + 1)                                                                    \
+            ACX_M16(ch_, actl[0][(u_) >> 1], Xn[(u_) & 1])                                                      \
+            ACX_NANO_AT(HV, 1, 6 * (u_) + 2)                                                                    \
+            ACX_M16(ch_, actl[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                \
+            ACX_NANO_AT(HV, 1, 6 * (u_) + 3)                                                                    \
+            ACX_M16(ch_, acth[0][(u_) >> 1], Xn[(u_) & 1])                                                      \
+            if ((u_) + 1 < Cfg::kSteps) ACX_TOUCH2(th_, tl_)                                                    \
+            ACX_NANO_AT(HV, 1, 6 * (u_) + 4)                                                                    \
+            ACX_M16(ch_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                \
+            if ((u_) + 3 < Cfg::kSteps) ch_ = ACX_W1_RD(base, (u_) + 3, 0);                                     \
+            ACX_NANO_AT(HV, 1, 6 * (u_) + 5)                                                                    \
             ACX_FENCE
 #pragma unroll
         for (int s = 0; s < Cfg::kSteps; s += 3) {
@@ -377,9 +369,22 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         ACX_FENCE
 #define ACX_P2_UNIT(i_, ch_, cl_, th_, tl_)                                                                     \
             ACX_FENCE                                                                                           \
-            ACX_P2_MFMA(i_, ch_, cl_)                                                                           \
+            ACX_M16(cl_, gh[0], acc[i_][0])                                                                     \
+            if ((i_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (i_) / Cfg::kDmaStride, g2) }          \
+            ACX_NANO_AT(HV, 0, 6 * (i_) + 0)                                                                    \
+            ACX_M16(cl_, gh[1], acc[i_][1])                                                                     \
+            if ((i_) + 3 < Cfg::kUnits) cl_ = ACX_W2_RD(base, (i_) + 3, 1);                                     \
+            ACX_NANO_AT(HV, 0, 6 * (i_) + 1)                                                                    \
+            ACX_M16(ch_, gl[0], acc[i_][0])                                                                     \
+            ACX_NANO_AT(HV, 0, 6 * (i_) + 2)                                                                    \
+            ACX_M16(ch_, gl[1], acc[i_][1])                                                                     \
+            ACX_NANO_AT(HV, 0, 6 * (i_) + 3)                                                                    \
+            ACX_M16(ch_, gh[0], acc[i_][0])                                                                     \
             if ((i_) + 1 < Cfg::kUnits) ACX_TOUCH2(th_, tl_)                                                    \
-            if ((i_) + 3 < Cfg::kUnits) { ch_ = ACX_W2_RD(base, (i_) + 3, 0); cl_ = ACX_W2_RD(base, (i_) + 3, 1); } \
+            ACX_NANO_AT(HV, 0, 6 * (i_) + 4)                                                                    \
+            ACX_M16(ch_, gh[1], acc[i_][1])                                                                     \
+            if ((i_) + 3 < Cfg::kUnits) ch_ = ACX_W2_RD(base, (i_) + 3, 0);                                     \
+            ACX_NANO_AT(HV, 0, 6 * (i_) + 5)                                                                    \
             ACX_FENCE
 #pragma unroll
         for (int i = 0; i < Cfg::kUnits; i += 3) {
@@ -426,13 +431,11 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #undef ACX_H8
 #undef ACX_FENCE
 #undef ACX_W1_RD
-#undef ACX_P1_MFMA
 #undef ACX_W2_RD
-#undef ACX_P2_MFMA
 #undef ACX_TOUCH2
 #undef ACX_BIAS_INIT
 #undef ACX_NANO_RANGE
-#undef ACX_AFTER_MFMA
+#undef ACX_NANO_AT
 #undef ACX_PACK_G
 #undef ACX_SEG_END
 
