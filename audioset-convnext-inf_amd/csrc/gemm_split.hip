@@ -434,21 +434,39 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
     {   _Pragma("unroll") for (int term = 0; term < 3; ++term)                                         \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
         _Pragma("unroll") for (int j = 0; j < 3; ++j) { ACX_MFMA16(AF, BF, j0, term, i, j) } }
-    // the same with the LDS-DMA pieces threaded in, one piece behind every second MFMA: first the B pieces of tile t+2,
-    // then -- behind one fence -- the A pieces of tile t+3 (the counted wait at the next barrier relies on this order)
-#define ACX_MFMA_HALF_DMA(AF, BF, j0, koffA, aslot, k0B, bslot)                                        \
+    // Behind a 16x16x32 MFMA two single-issue instructions are free (tools/lab/coissue2.hip): the fragment reads and the LDS-DMA
+    // pieces are spread over the MFMA gaps, one read per gap, instead of standing in clumps between the halves.
+    // half 0 of tile t: behind MFMA mc < 6 the read of weight fragment 3 + mc / 2 (hi / lo) of tile t itself -- the registers
+    // half 1 will use (they were busy until the previous tile's half 1 ended)
+#define ACX_MFMA_HALF0_RD(AF, BF, BFH, bcur)                                                           \
     {   _Pragma("unroll") for (int term = 0; term < 3; ++term)                                         \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
         _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                \
             const int mc = (term * MI + i) * 3 + j;                                                    \
+            ACX_MFMA16(AF, BF, 0, term, i, j)                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            if (mc < 6) BFH[mc >> 1][mc & 1] = *reinterpret_cast<const f32x4*>((bcur) + (3 + (mc >> 1)) * 16 * kSRowBytes + ((mc & 1) ? foff_lo : foff_hi)); \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+        } }
+    // half 1 of tile t: behind MFMA mc < 14 one fragment read of tile t + 1 (8 activation, 6 weight: the registers half 0 of
+    // the next tile will use), behind every second MFMA one LDS-DMA piece: first the B pieces of tile t+2, then -- behind one
+    // fence -- the A pieces of tile t+3 (the counted wait at the next barrier relies on this order)
+#define ACX_MFMA_HALF1_DMA_RD(AF, BF, ANX, BLX, abn_, bbn_, koffA, aslot, k0B, bslot)                  \
+    {   _Pragma("unroll") for (int term = 0; term < 3; ++term)                                         \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                \
+            const int mc = (term * MI + i) * 3 + j;                                                    \
+            ACX_MFMA16(AF, BF, 3, term, i, j)                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
             if ((mc & 1) == 0) {                                                                       \
                 const int pc = mc >> 1;                                                                \
-                if (pc == B_DMA) __builtin_amdgcn_sched_barrier(0);                                    \
                 if (pc < B_DMA) lds_dma16_s(b_src[pc] + (k0B), b_dst + (bslot) * B_TILE + pc * 8 * kSRowBytes); \
                 else if (pc < A_DMA + B_DMA)                                                           \
                     lds_dma16_s(a_src[pc - B_DMA] + (koffA), a_dst + (aslot) * A_TILE + (pc - B_DMA) * 8 * kSRowBytes); \
             }                                                                                          \
-            ACX_MFMA16(AF, BF, j0, term, i, j)                                                         \
+            if (mc < 8) ANX[mc >> 1][mc & 1] = *reinterpret_cast<const f32x4*>((abn_) + (mc >> 1) * 16 * kSRowBytes + ((mc & 1) ? foff_lo : foff_hi)); \
+            else if (mc < 14) BLX[(mc - 8) >> 1][mc & 1] = *reinterpret_cast<const f32x4*>((bbn_) + ((mc - 8) >> 1) * 16 * kSRowBytes + ((mc & 1) ? foff_lo : foff_hi)); \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
         } }
 #define ACX_DMA_A(koffA, aslot)                                                                        \
     {   _Pragma("unroll") for (int i = 0; i < A_DMA; ++i)                                              \
@@ -473,7 +491,6 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
         const char* bb = Bs + b_frag_off;
         ACX_RD_A(A0, ab)
         ACX_RD_B(BL, bb, 0)
-        ACX_RD_B(BH, bb, 3)
     }
     // steady state, tile t (A slot t % 3, B slot t & 1), activation fragments AC (this tile) / AN (the next one):
     //   MFMA half 0 | counted wait + barrier (tile t+1 landed, tile t read by every wave) | rd A(t+1), B 0-2 (t+1) |
@@ -483,24 +500,21 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
     {                                                                                                  \
         const int a_nxt = a_cur == 2 ? 0 : a_cur + 1;                                                  \
         const char* abn = As + a_nxt * A_TILE + a_frag_off;                                            \
+        const char* bbc = Bs + ((kt_) & 1) * B_TILE + b_frag_off;                                      \
         const char* bbn = Bs + (((kt_) + 1) & 1) * B_TILE + b_frag_off;                                \
         const long long kb = (long long)ktile((kt_) + 2) * 4;                                          \
         const long long ka = a_koff(ktile((kt_) + 3));                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        ACX_MFMA_HALF(AC, BL, 0)                                                                       \
+        ACX_MFMA_HALF0_RD(AC, BL, BH, bbc)                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        ACX_TOUCH_B(BH)                                                                                \
+        ACX_TOUCH_B(BH)                     /* tile t is fully in registers before its slots are given away */ \
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_DMA) : "memory");                                  \
         __builtin_amdgcn_s_barrier();                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        ACX_RD_A(AN, abn)                                                                              \
-        ACX_RD_B(BL, bbn, 0)                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        ACX_MFMA_HALF_DMA(AC, BH, 3, ka, a_cur, kb, (kt_) & 1)                                         \
+        ACX_MFMA_HALF1_DMA_RD(AC, BH, AN, BL, abn, bbn, ka, a_cur, kb, (kt_) & 1)                      \
         __builtin_amdgcn_sched_barrier(0);                                                             \
         ACX_TOUCH_A(AN)                                                                                \
         ACX_TOUCH_B(BL)                                                                                \
-        ACX_RD_B(BH, bbn, 3)                                                                           \
         a_cur = a_nxt;                                                                                 \
     }
     int kt = 0;
@@ -508,8 +522,11 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
         ACX_BODY(kt, A0, A1)
         ACX_BODY(kt + 1, A1, A0)
     }
-    ACX_BODY(kt, A0, A1)                  // kt = nk - 2: the last tile's fragments land in A1 / BL / BH
-    ACX_MFMA_HALF(A1, BL, 0)
+    ACX_BODY(kt, A0, A1)                  // kt = nk - 2: the last tile's fragments land in A1 / BL
+    {
+        const char* bbc = Bs + ((nk - 1) & 1) * B_TILE + b_frag_off;
+        ACX_MFMA_HALF0_RD(A1, BL, BH, bbc)
+    }
     ACX_MFMA_HALF(A1, BH, 3)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the repeated requests of the last iterations: nothing may still be writing the LDS when the workgroup ends
 #undef ACX_BODY
@@ -517,7 +534,8 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
 #undef ACX_RD_B
 #undef ACX_MFMA16
 #undef ACX_MFMA_HALF
-#undef ACX_MFMA_HALF_DMA
+#undef ACX_MFMA_HALF0_RD
+#undef ACX_MFMA_HALF1_DMA_RD
 #undef ACX_DMA_A
 #undef ACX_DMA_B
 #undef ACX_TOUCH_A
