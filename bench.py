@@ -54,11 +54,10 @@ HBM_COPY_GBS = 6290.0          # the same guide: what a float4 copy reaches on t
 MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA, dense (no xf32 on gfx950)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA at the nominal 2.4 GHz
 # Shader clock the chip holds inside the split-fp16 MFMA kernels under load: 1.69 GHz stamped with s_memtime / s_memrealtime
-# in round 1's diagnostic builds, 1.74-1.85 GHz by GRBM_GUI_ACTIVE / duration in round 3's PMC passes
-# (profiles/r03_m_split_pmc_per_kernel.csv); bare fp16 MFMA loops on random operands hold 1.6 GHz
-# (profiles/r03_i_mfma_shape_rates.txt).  Reported next to `frac` as extra information; `peak` and `frac` themselves stay on
-# the nominal 2.4 GHz figure.
-SPLIT_SHADER_CLOCK_GHZ = 1.69
+# in round 1's diagnostic builds (32x32x16 MFMAs), 1.94-2.11 GHz by GRBM_GUI_ACTIVE / duration in round 3's PMC passes of the
+# 16x16x32 kernels (profiles/r03_t_split_pmc_per_kernel.csv, r03_q_*: it differs box to box and falls as the loop gets tighter).
+# Reported next to `frac` as extra information; `peak` and `frac` themselves stay on the nominal 2.4 GHz figure.
+SPLIT_SHADER_CLOCK_GHZ = 1.95
 DIMS, DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
 
 
@@ -455,7 +454,7 @@ def main():
                             "algorithmic_bytes_per_launch": g["bytes"] / g["launches"]}
         if split:
             pk = 1024 * 1024 * SPLIT_SHADER_CLOCK_GHZ / 1e3 / 3.0     # SIMDs x flop/cycle/SIMD x GHz / 3 -> TFLOP/s algorithmic
-            line["roofline"].update({"shader_clock_GHz_measured_in_lab": SPLIT_SHADER_CLOCK_GHZ,
+            line["roofline"].update({"shader_clock_GHz_in_kernel_pmc": SPLIT_SHADER_CLOCK_GHZ,
                                      "peak_at_that_clock": pk, "frac_at_that_clock": ach / pk})
         if bf16:        # at bf16 rates the GEMMs are bound by their HBM traffic (the hidden activation), not the matrix pipe
             gbs = g["bytes"] / g["launches"] / avg_launch_s / 1e9
