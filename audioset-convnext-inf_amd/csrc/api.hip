@@ -146,7 +146,7 @@ static float hidden_scale_for(const std::vector<float>& w1, const std::vector<fl
     }
     if (!(worst > 0.0) || !std::isfinite(worst)) return 1.f;
     int e = (int)std::floor(std::log2(65000.0 / worst));
-    e = e > 12 ? 12 : (e < -40 ? -40 : e);
+    e = e > 12 ? 12 : (e < -24 ? -24 : e);      // 2^-24: every scaled GELU coefficient stays a normal fp32 number (split_math.h, gelu_k3)
     return std::ldexp(1.0f, e);
 }
 

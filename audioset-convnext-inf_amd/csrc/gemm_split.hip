@@ -257,11 +257,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
 
     const float sinv = p.sinv;
     if (EPI == 1) {
-        GeluConsts gk;          // GELU of v = a * sinv, result x p.hscale (see split_math.h)
-        gk.ps = 0.3275911f * 0.70710678f * sinv;
-        gk.cq = 0.84932180f * sinv;       // sqrt(log2(e) / 2): exp(-v^2 / 2) = exp2(-(cq a)^2)
-        gk.ca = -0.5f * sinv * p.hscale;
-        gk.cb = sinv * p.hscale;
+        const GeluK3 gk = gelu_k3(sinv, p.hscale);      // GELU of v = a * sinv, result x p.hscale (split_math.h, third form)
         const float binv = 1.0f / sinv;     // a power of two
         // ---- GELU epilogue, D = W A^T: lane = row m, registers r = 4q+e hold n = 8q + 4hh + e ------------------
         // One S16 block (8 n) = [hi x8][lo x8] is shared by the lane pair (l31, hh=0/1): after a permlane32 swap
@@ -281,12 +277,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
                     unsigned xh[2], xl[2];
 #pragma unroll
                     for (int e2 = 0; e2 < 2; ++e2) {      // acc holds v / sinv - bias / sinv: add the pre-scaled bias first
-                        f32x2 a2, av, t, ex, g;
-                        a2.x = acc[i][j][4 * q + 2 * e2] + b4[2 * e2] * binv;
-                        a2.y = acc[i][j][4 * q + 2 * e2 + 1] + b4[2 * e2 + 1] * binv;
-                        gelu_piece1(a2, gk, av, t, ex);
-                        gelu_piece2(a2, av, t, ex, gk, g);
-                        gelu_piece3(g, xh[e2], xl[e2]);
+                        const float ax = acc[i][j][4 * q + 2 * e2] + b4[2 * e2] * binv;
+                        const float ay = acc[i][j][4 * q + 2 * e2 + 1] + b4[2 * e2 + 1] * binv;
+                        gelu3_pair(gk, ax, ay, xh[e2], xl[e2]);
                     }
                     // low lanes: (own hi, partner hi); high lanes: (partner lo, own lo)
                     auto r0 = __builtin_amdgcn_permlane32_swap(xh[0], xl[0], false, false);
@@ -545,11 +538,7 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
     // ---- epilogues: lane (l15, g4) owns row m = m0 + 64 wm + 16 i + l15, columns nb + 4 g4 .. + 3 of block (i, j) ------
     const float sinv = p.sinv;
     if (EPI == 1) {
-        GeluConsts gk;          // GELU of v = a * sinv, result x p.hscale (see split_math.h)
-        gk.ps = 0.3275911f * 0.70710678f * sinv;
-        gk.cq = 0.84932180f * sinv;
-        gk.ca = -0.5f * sinv * p.hscale;
-        gk.cb = sinv * p.hscale;
+        const GeluK3 gk = gelu_k3(sinv, p.hscale);      // GELU of v = a * sinv, result x p.hscale (split_math.h, third form)
         const float binv = 1.0f / sinv;     // a power of two
         // One S16 block (8 n) = [hi x8][lo x8] is shared by the lanes (g4, g4 ^ 1) of a pixel row: after a permlane16
         // swap the even lane holds all 8 hi halves and the odd lane all 8 lo halves -> one 16-B store each.
@@ -566,12 +555,9 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
                 unsigned xh[2], xl[2];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {      // acc holds v / sinv - bias / sinv: add the pre-scaled bias first
-                    f32x2 a2, av, t, ex, g;
-                    a2.x = acc[i][j][2 * e2] + b4[2 * e2] * binv;
-                    a2.y = acc[i][j][2 * e2 + 1] + b4[2 * e2 + 1] * binv;
-                    gelu_piece1(a2, gk, av, t, ex);
-                    gelu_piece2(a2, av, t, ex, gk, g);
-                    gelu_piece3(g, xh[e2], xl[e2]);
+                    const float ax = acc[i][j][2 * e2] + b4[2 * e2] * binv;
+                    const float ay = acc[i][j][2 * e2 + 1] + b4[2 * e2 + 1] * binv;
+                    gelu3_pair(gk, ax, ay, xh[e2], xl[e2]);
                 }
                 // even rows of 16 lanes: (own hi, partner hi); odd rows: (partner lo, own lo)
                 auto r0 = __builtin_amdgcn_permlane16_swap(xh[0], xl[0], false, false);

@@ -7,7 +7,7 @@
 //               normalised activations (x 2^11) as hi/lo halves, resident in C/2 VGPRs: lane (px, h) holds
 //               channels 16s + 8h .. +7 of k-step s
 //     GELU      on the 16 accumulator registers (bias pre-loaded as the initial accumulator), x 2^h, split into
-//               hi/lo halves -- SCALAR fp32 math, 15 VALU per element (split_math.h, gelu_micro2).  The file is built
+//               hi/lo halves -- SCALAR fp32 math, 11 VALU per element (split_math.h, gelu3_nano).  The file is built
 //               with -fno-slp-vectorize: beside MFMAs a packed-FP32 instruction costs far more than the two scalar
 //               ones it replaces (round 2 ran this kernel on v_pk_fma_f32 / v_pk_mul_f32: 104 of them per 36 MFMAs,
 //               0.25 of the matrix peak; profiles/r03_a_coissue_table.txt prices one v_pk_fma_f32 in an MFMA gap at +18 cycles)
@@ -176,8 +176,9 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
     const int w1row = l31 * (4 * C);
     const int sw2 = (l31 >> 1) & 7;
     const int w2row = l31 * 128;
-    GeluK2 gk = gelu_k2(sinv1, hscale);
-    gelu_k2_to_vgprs(gk);
+    GeluK3 gk = gelu_k3(sinv1, hscale);
+    gelu_k3_to_vgprs(gk);
+    constexpr int kGeluSteps = 8 * kGelu3Nano;
 
 #define ACX_H8(v_) __builtin_bit_cast(h8, v_)
 #define ACX_G4(g_, s_) __builtin_bit_cast(h8, uint4{g_[4 * (s_)], g_[4 * (s_) + 1], g_[4 * (s_) + 2], g_[4 * (s_) + 3]})
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
 #define ACX_W1_RD(w1p_, s_, pl_) (*reinterpret_cast<const f32x4*>((w1p_) + w1row + (((2 * (2 * (s_) + hh) + (pl_)) ^ sw1) << 4)))
     // MFMA number m_ of an iteration (kTot of them) is followed, behind scheduling fences, by its share of the 64 GELU
     // micro-steps the iteration carries: steps [64 m / kTot, 64 (m + 1) / kTot)
-#define ACX_AFTER(m_) ACX_FENCE if constexpr (HV) { ACX_MICRO(Xin, gnh, gnl, 64 * (m_) / kTot, 64 * ((m_) + 1) / kTot) } ACX_FENCE
+#define ACX_AFTER(m_) ACX_FENCE if constexpr (HV) { ACX_MICRO(Xin, gnh, gnl, kGeluSteps * (m_) / kTot, kGeluSteps * ((m_) + 1) / kTot) } ACX_FENCE
 #define ACX_P1_MFMA(Xacc_, s_, ah_, al_, m0_)                                                                   \
         Xacc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ACX_H8(al_), ACX_H8(acth[s_]), Xacc_, 0, 0, 0);          \
         ACX_AFTER((m0_) + 0)                                                                                    \
@@ -214,21 +215,19 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
             const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j_) + 8 * q + 4 * hh);                 \
             Xacc_[4 * q + 0] = bq[0]; Xacc_[4 * q + 1] = bq[1]; Xacc_[4 * q + 2] = bq[2]; Xacc_[4 * q + 3] = bq[3]; \
         }
-    // GELU micro-steps [from, to) of the 64 that turn X_ into the packed halves gh_ / gl_ (8 words each: the B operand of the
-    // next iteration's phase 2, k-step s' = words 4 s' .. 4 s' + 3): step m works on register pair 2 (m / 16) + (m & 1) -- two
-    // pairs alternate, so neighbouring micro-steps do not depend on each other -- and is step (m % 16) / 2 of that pair's eight
+    // GELU steps [from, to) of the kGeluSteps = 8 x 22 single instructions that turn X_ into the packed halves gh_ / gl_ (8 words
+    // each: the B operand of the next iteration's phase 2, k-step s' = words 4 s' .. 4 s' + 3): step m works on register pair
+    // 2 (m / 44) + (m & 1) -- two pairs alternate, so neighbouring steps do not depend on each other -- and is step (m % 44) / 2
+    // of that pair's twenty-two (split_math.h, gelu3_nano)
+#define ACX_NANO_CASE(I_, X_, gh_, gl_) else if (st_ == (I_)) gelu3_nano<(I_)>(gs_, gk, X_[2 * pr_], X_[2 * pr_ + 1], gh_[pr_], gl_[pr_]);
 #define ACX_MICRO(X_, gh_, gl_, from_, to_)                                                                     \
         _Pragma("unroll") for (int mm_ = (from_); mm_ < (to_); ++mm_) {                                         \
-            const int pr_ = 2 * (mm_ / 16) + (mm_ & 1), st_ = (mm_ % 16) >> 1;                                  \
-            GeluState2& gs_ = (mm_ & 1) ? gsB : gsA;                                                            \
-            if (st_ == 0) { gs_.ax = X_[2 * pr_]; gs_.ay = X_[2 * pr_ + 1]; gelu_micro2<0>(gs_, gk, gh_[pr_], gl_[pr_]); } \
-            else if (st_ == 1) gelu_micro2<1>(gs_, gk, gh_[pr_], gl_[pr_]);                                     \
-            else if (st_ == 2) gelu_micro2<2>(gs_, gk, gh_[pr_], gl_[pr_]);                                     \
-            else if (st_ == 3) gelu_micro2<3>(gs_, gk, gh_[pr_], gl_[pr_]);                                     \
-            else if (st_ == 4) gelu_micro2<4>(gs_, gk, gh_[pr_], gl_[pr_]);                                     \
-            else if (st_ == 5) gelu_micro2<5>(gs_, gk, gh_[pr_], gl_[pr_]);                                     \
-            else if (st_ == 6) gelu_micro2<6>(gs_, gk, gh_[pr_], gl_[pr_]);                                     \
-            else gelu_micro2<7>(gs_, gk, gh_[pr_], gl_[pr_]);                                                   \
+            const int pr_ = 2 * (mm_ / (2 * kGelu3Nano)) + (mm_ & 1), st_ = (mm_ % (2 * kGelu3Nano)) >> 1;      \
+            GeluState3& gs_ = (mm_ & 1) ? gsB : gsA;                                                            \
+            if (st_ == 0) gelu3_nano<0>(gs_, gk, X_[2 * pr_], X_[2 * pr_ + 1], gh_[pr_], gl_[pr_]);             \
+            ACX_NANO_CASE(1, X_, gh_, gl_) ACX_NANO_CASE(2, X_, gh_, gl_) ACX_NANO_CASE(3, X_, gh_, gl_) ACX_NANO_CASE(4, X_, gh_, gl_) ACX_NANO_CASE(5, X_, gh_, gl_) ACX_NANO_CASE(6, X_, gh_, gl_) ACX_NANO_CASE(7, X_, gh_, gl_) \
+            ACX_NANO_CASE(8, X_, gh_, gl_) ACX_NANO_CASE(9, X_, gh_, gl_) ACX_NANO_CASE(10, X_, gh_, gl_) ACX_NANO_CASE(11, X_, gh_, gl_) ACX_NANO_CASE(12, X_, gh_, gl_) ACX_NANO_CASE(13, X_, gh_, gl_) ACX_NANO_CASE(14, X_, gh_, gl_) \
+            ACX_NANO_CASE(15, X_, gh_, gl_) ACX_NANO_CASE(16, X_, gh_, gl_) ACX_NANO_CASE(17, X_, gh_, gl_) ACX_NANO_CASE(18, X_, gh_, gl_) ACX_NANO_CASE(19, X_, gh_, gl_) ACX_NANO_CASE(20, X_, gh_, gl_) ACX_NANO_CASE(21, X_, gh_, gl_) \
         }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first tile: W1c(0..2), W2c(0), y landed ...
@@ -305,7 +304,7 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
         // with Gcur = G(j) and builds Gnew = G(j+1).
         f32x16 Xa, Xb;
         unsigned gah[8], gal[8], gbh[8], gbl[8];      // G as packed fp16 pairs: words 4 s' .. 4 s' + 3 = k-step s'
-        GeluState2 gsA, gsB;
+        GeluState3 gsA, gsB;
         f32x4 xr[C / 8];      // the residual x rows of the tile, requested in the last iteration
         {   // X(0) -> G(0) = Ga, X(1) -> Xa; nothing to overlap with yet
             ACX_BIAS_INIT(Xb, 0)
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
                 const f32x4 ah = ACX_W1_RD(w1buf, s, 0), al = ACX_W1_RD(w1buf, s, 1);
                 ACX_P1_MFMA_PLAIN(Xb, s, ah, al)
             }
-            ACX_MICRO(Xb, gah, gal, 0, 64)
+            ACX_MICRO(Xb, gah, gal, 0, kGeluSteps)
             ACX_BIAS_INIT(Xa, 1)
 #pragma unroll
             for (int s = 0; s < Cfg::kSteps; ++s) {

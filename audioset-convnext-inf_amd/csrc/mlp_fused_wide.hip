@@ -22,8 +22,8 @@
 //               LDS holds a ring of three segments: one being multiplied, one landed or landing, one being requested.
 //   schedule    segment 2k-1: phase 1 of chunk k    X^T[32 hidden x 32 px] = W1c . LN(y)^T     3 C/16 MFMA pairs (one per pixel block)
 //               segment 2k  : phase 2 of chunk k-1  out^T[C x 32 px] += W2c . G(k-1)            3 C/16 MFMA pairs
-//               GELU + hi/lo split of X(k) -> G(k): 30 single-instruction "nano-steps" per register pair (split_math.h,
-//               gelu_nano), half of the pairs dealt over the MFMAs of segment 2k, the other half over those of segment
+//               GELU + hi/lo split of X(k) -> G(k): 22 single-instruction "nano-steps" per register pair (split_math.h,
+//               gelu3_nano), half of the pairs dealt over the MFMAs of segment 2k, the other half over those of segment
 //               2k+1.  One wave per SIMD issues both streams: about five single-issue instructions ride for free behind
 //               32 cycles of matrix work (a 32x32x16 MFMA then, a pair of 16x16x32 now), every further one costs ~5 cycles
 //               (profiles/r03_d_coissue_table_full.txt), so each gap behind a pair gets at most four slots, fewer where an LDS-DMA piece or the fragment reads of the next unit already
@@ -79,7 +79,7 @@ struct WideCfg {
     static constexpr int kMfmas = 3 * kUnits * PT;          // MFMAs per segment
     static constexpr int kDmaStride = kUnits / kPieces;     // one LDS-DMA piece every kDmaStride units
     // GELU nano-steps (single instructions, split_math.h) a segment carries: half of a pixel tile's 8 register pairs
-    static constexpr int kNano = 4 * kGeluNano * PT;
+    static constexpr int kNano = 4 * kGelu3Nano * PT;
     static_assert(C % 32 == 0 && kSteps == kUnits && kUnits % kPieces == 0, "unit / piece bookkeeping");
     // Issue budget of the gap BEHIND MFMA m of a segment (unit m / 6, position m % 6: the three terms x the two pixel blocks).
     // Behind a 16x16x32 MFMA (16 matrix cycles) TWO single-issue instructions are free and every further one costs ~5 cycles;
@@ -97,8 +97,8 @@ struct WideCfg {
         const int c0 = (u % kDmaStride == 0) ? 1 : 2;
         return cum_cap_units(u) + (pos == 0 ? c0 : pos == 1 ? c0 + 1 : pos == 2 ? c0 + 3 : pos == 3 ? c0 + 5 : pos == 4 ? c0 + 6 : c0 + 7);
     }
-    // what does not fit the gaps (C = 192: 120 nano-steps per segment, 102 slots) is issued at the top of the segment, right
-    // behind the reads of its first three fragment pairs
+    // what does not fit the gaps is issued at the top of the segment, right behind the reads of its first three fragment pairs
+    // (nothing since the GELU is 22 steps per pair: 88 per segment against 102 slots at C = 192; it was 120 with the 30-step form)
     static constexpr int kCapTotal = cum_cap_units(kUnits);
     static constexpr int kNanoHead = kNano > kCapTotal ? ((kNano - kCapTotal + 1) / 2) * 2 : 0;
     __host__ __device__ static constexpr int nano_end(int m) {      // nano-steps issued once the gap behind MFMA m is done
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         for (int pl = 0; pl < 2; ++pl) w1off[q][pl] = l15 * (4 * C) + (((8 * q + 2 * g4 + pl) ^ l15) << 4);
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) w2off[pl] = l15 * 128 + (((2 * g4 + pl) ^ acx_swz8(l15)) << 4);
-    const GeluK2 gk = gelu_k2(sinv1, hscale);
+    const GeluK3 gk = gelu_k3(sinv1, hscale);
 
 #define ACX_H8(v_) __builtin_bit_cast(h8, v_)
 #define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
@@ -238,44 +238,38 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #define ACX_M16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ACX_H8(a_), ACX_H8(b_), c_, 0, 0, 0);
     // phase-2 unit i_ = block cb of 16 out channels; K = the chunk's 32 hidden units in ONE step
 #define ACX_W2_RD(base_, i_, pl_) (*reinterpret_cast<const f32x4*>((base_) + (i_) * (16 * 128) + w2off[pl_]))
-    // nano-steps [from, to) of the kNano that segment half half_ carries: step ng_ is instruction ng_ % 30 of register pair
-    // 4 half_ + ng_ / 30 (split_math.h, gelu_nano): pair after pair, in order.  Pair pr = 4 pb + 2 hb + e covers registers
+    // nano-steps [from, to) of the kNano that segment half half_ carries: step ng_ is instruction (ng_ % 44) / 2 of register pair
+    // 4 half_ + 2 (ng_ / 44) + (ng_ & 1) (split_math.h, gelu3_nano): pair after pair, in order.  Pair pr = 4 pb + 2 hb + e covers registers
     // 2 e, 2 e + 1 of X block 2 pb + hb: hidden units 16 hb + 4 g4 + 2 e, + 1 of pixel block pb
+#define ACX_NANO_ARGS gsv[w_], gk, Xv[(2 * pr_) >> 2][(2 * pr_) & 3], Xv[(2 * pr_) >> 2][((2 * pr_) & 3) + 1], uh[0][pr_], ul[0][pr_]
+#define ACX_NANO_CASE(I_) else if (st_ == (I_)) gelu3_nano<(I_)>(ACX_NANO_ARGS);
 #define ACX_NANO_RANGE(half_, from_, to_)                                                                       \
         _Pragma("unroll") for (int ng_ = (from_); ng_ < (to_); ++ng_) {                                         \
             /* two register pairs in flight, their instructions alternating: consecutive nano-steps never depend on each other */ \
-            const int j_ = ng_ % (2 * kGeluNano), w_ = j_ & 1, mt_ = 0;                                         \
-            const int pr_ = 4 * (half_) + 2 * (ng_ / (2 * kGeluNano)) + w_, st_ = j_ >> 1;                      \
-            if (st_ == 0) { gsv[w_].ax = Xv[(2 * pr_) >> 2][(2 * pr_) & 3]; gsv[w_].ay = Xv[(2 * pr_) >> 2][((2 * pr_) & 3) + 1]; gelu_nano<0>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]); } \
-            else if (st_ == 1) gelu_nano<1>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 2) gelu_nano<2>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 3) gelu_nano<3>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 4) gelu_nano<4>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 5) gelu_nano<5>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 6) gelu_nano<6>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 7) gelu_nano<7>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 8) gelu_nano<8>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 9) gelu_nano<9>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 10) gelu_nano<10>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 11) gelu_nano<11>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 12) gelu_nano<12>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 13) gelu_nano<13>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 14) gelu_nano<14>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 15) gelu_nano<15>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 16) gelu_nano<16>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 17) gelu_nano<17>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 18) gelu_nano<18>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 19) gelu_nano<19>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 20) gelu_nano<20>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 21) gelu_nano<21>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 22) gelu_nano<22>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 23) gelu_nano<23>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 24) gelu_nano<24>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 25) gelu_nano<25>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 26) gelu_nano<26>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 27) gelu_nano<27>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 28) gelu_nano<28>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
-            else if (st_ == 29) gelu_nano<29>(gsv[w_], gk, uh[mt_][pr_], ul[mt_][pr_]);                                   \
+            const int j_ = ng_ % (2 * kGelu3Nano), w_ = j_ & 1;                                                 \
+            const int pr_ = 4 * (half_) + 2 * (ng_ / (2 * kGelu3Nano)) + w_, st_ = j_ >> 1;                     \
+            if (st_ == 0) gelu3_nano<0>(ACX_NANO_ARGS);                                                         \
+            ACX_NANO_CASE(1)                                                                                     \
+            ACX_NANO_CASE(2)                                                                                     \
+            ACX_NANO_CASE(3)                                                                                     \
+            ACX_NANO_CASE(4)                                                                                     \
+            ACX_NANO_CASE(5)                                                                                     \
+            ACX_NANO_CASE(6)                                                                                     \
+            ACX_NANO_CASE(7)                                                                                     \
+            ACX_NANO_CASE(8)                                                                                     \
+            ACX_NANO_CASE(9)                                                                                     \
+            ACX_NANO_CASE(10)                                                                                    \
+            ACX_NANO_CASE(11)                                                                                    \
+            ACX_NANO_CASE(12)                                                                                    \
+            ACX_NANO_CASE(13)                                                                                    \
+            ACX_NANO_CASE(14)                                                                                    \
+            ACX_NANO_CASE(15)                                                                                    \
+            ACX_NANO_CASE(16)                                                                                    \
+            ACX_NANO_CASE(17)                                                                                    \
+            ACX_NANO_CASE(18)                                                                                    \
+            ACX_NANO_CASE(19)                                                                                    \
+            ACX_NANO_CASE(20)                                                                                    \
+            ACX_NANO_CASE(21)                                                                                    \
         }
 #define ACX_TOUCH2(h_, l_) asm volatile("" :: "v"(h_), "v"(l_));
 #define ACX_BIAS_INIT(j_)                                                                                       \
@@ -303,7 +297,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     f32x4 Xn[4], Xv[4];           // X^T blocks 2 pb + hb (16 hidden x 16 pixels each): Xn being accumulated by phase 1; Xv: the previous chunk's, input of the GELU
     f32x4 gh[2], gl[2];           // G(k - 1): B operand of phase 2 per pixel block, hi / lo halves
     unsigned uh[PT][8], ul[PT][8];
-    GeluState2 gsv[2];
+    GeluState3 gsv[2];
 
     // one phase-1 segment: X = b1 + W1c . LN(y)^T for chunk k_, image in ring slot grp_, requesting segment seg_ + 2
     auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
@@ -435,6 +429,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #undef ACX_TOUCH2
 #undef ACX_BIAS_INIT
 #undef ACX_NANO_RANGE
+#undef ACX_NANO_CASE
+#undef ACX_NANO_ARGS
 #undef ACX_NANO_AT
 #undef ACX_PACK_G
 #undef ACX_SEG_END

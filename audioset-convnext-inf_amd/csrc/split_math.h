@@ -209,6 +209,78 @@ __device__ __forceinline__ void gelu_micro2(GeluState2& s, const GeluK2 k, unsig
     }
 }
 
+// ---- GELU + split, third form (round 3): 11 vector instructions per element, ONE transcendental --------------------------
+//   erfc(|v| / sqrt 2) ~= E(|v|) = exp2(-|v| Q(|v|)),  Q of degree 4 (five coefficients, leading one positive: -|v| Q -> -inf
+//   for large |v|, E -> 0 without a clamp; E(0) = 1 exactly, so the relative accuracy near 0 is kept)
+//   gelu(v) = 0.5 v + 0.5 |v| (1 - E):  minimax fit of 0.5 |v| (E - erfc) over [0, 9] (tools/lab/fit_gelu.py):
+//   |gelu error| <= 5.4e-7 in exact arithmetic, <= 1e-6 as evaluated in fp32 (the fp32 rounding of a result near 4 is
+//   4.8e-7), against 2.1e-7 for A&S 7.1.26 above -- whose 1 / (1 + p |v|) and exp(-v^2 / 2) cost a second transcendental
+//   (8 issue cycles each against 2-4 for an FMA, profiles/r03_c_valu_opcode_costs.txt) and four more instructions.
+// Unit: z = a (sinv 0.5 kH) = 0.5 kH v, the linear term of the result itself (one exact power-of-two multiply):
+//   g = gelu(v) kH = z + |z| (1 - E),   exp2 argument = |z| (K0 + K1 |z| + ... + K4 |z|^4),  Kj = -cj / (0.5 kH)^(j+1)
+// (exact scalings of the five constants; 0.5 kH = 2^-25 .. 2^11 keeps every Kj a normal number, api.hip hidden_scale_for).
+// For v << 0 the two terms cancel with an absolute error of |v| kH 2^-25 -- what the reference's own fp32 evaluation of
+// 0.5 v (1 + erf) carries there.  The fp32 -> fp16 hi / lo split is v_cvt_pk_f16_f32 + v_fma_mix_f32 (g - float(hi) in one
+// instruction per element, straight from the packed hi halves) + v_cvt_pk_f16_f32.  TWENTY-TWO single-instruction steps per
+// register pair (two values), four registers of state.
+struct GeluK3 { float zs, k0, k1, k2, k3, k4; };
+__device__ __forceinline__ GeluK3 gelu_k3(float sinv, float kh) {
+    GeluK3 k;
+    const float h = 0.5f * kh, ih = 1.0f / h;       // powers of two
+    k.zs = sinv * h;
+    float s = ih;
+    k.k0 = -1.1510010957717896f * s; s *= ih;
+    k.k1 = -0.4595935642719269f * s; s *= ih;
+    k.k2 = -0.05214935168623924f * s; s *= ih;
+    k.k3 = 0.00719997426494956f * s; s *= ih;
+    k.k4 = -0.0004882981302216649f * s;
+    return k;
+}
+// two waves per SIMD: constants in VGPRs (see gelu_k2_to_vgprs)
+__device__ __forceinline__ void gelu_k3_to_vgprs(GeluK3& k) {
+    asm volatile("" : "+v"(k.zs), "+v"(k.k0), "+v"(k.k1), "+v"(k.k2), "+v"(k.k3), "+v"(k.k4));
+}
+struct GeluState3 { float zx, zy, qx, qy; };
+constexpr int kGelu3Nano = 22;      // steps per register pair
+// step I of the pair (ax, ay) -> packed halves (hi, lo); ax / ay are read by steps 0 and 1 only
+template <int I>
+__device__ __forceinline__ void gelu3_nano(GeluState3& s, const GeluK3 k, const float ax, const float ay, unsigned& hi, unsigned& lo) {
+    if constexpr (I == 0) s.zx = ax * k.zs;
+    else if constexpr (I == 1) s.zy = ay * k.zs;
+    else if constexpr (I == 2) s.qx = __builtin_fmaf(__builtin_fabsf(s.zx), k.k4, k.k3);
+    else if constexpr (I == 3) s.qy = __builtin_fmaf(__builtin_fabsf(s.zy), k.k4, k.k3);
+    else if constexpr (I == 4) s.qx = __builtin_fmaf(s.qx, __builtin_fabsf(s.zx), k.k2);
+    else if constexpr (I == 5) s.qy = __builtin_fmaf(s.qy, __builtin_fabsf(s.zy), k.k2);
+    else if constexpr (I == 6) s.qx = __builtin_fmaf(s.qx, __builtin_fabsf(s.zx), k.k1);
+    else if constexpr (I == 7) s.qy = __builtin_fmaf(s.qy, __builtin_fabsf(s.zy), k.k1);
+    else if constexpr (I == 8) s.qx = __builtin_fmaf(s.qx, __builtin_fabsf(s.zx), k.k0);
+    else if constexpr (I == 9) s.qy = __builtin_fmaf(s.qy, __builtin_fabsf(s.zy), k.k0);
+    else if constexpr (I == 10) s.qx *= __builtin_fabsf(s.zx);
+    else if constexpr (I == 11) s.qy *= __builtin_fabsf(s.zy);
+    else if constexpr (I == 12) s.qx = __builtin_amdgcn_exp2f(s.qx);
+    else if constexpr (I == 13) s.qy = __builtin_amdgcn_exp2f(s.qy);
+    else if constexpr (I == 14) s.qx = 1.0f - s.qx;
+    else if constexpr (I == 15) s.qy = 1.0f - s.qy;
+    else if constexpr (I == 16) s.qx = __builtin_fmaf(__builtin_fabsf(s.zx), s.qx, s.zx);     // g
+    else if constexpr (I == 17) s.qy = __builtin_fmaf(__builtin_fabsf(s.zy), s.qy, s.zy);
+    else if constexpr (I == 18) { f32x2 g; g.x = s.qx; g.y = s.qy; hi = __builtin_bit_cast(unsigned, __builtin_convertvector(g, h2)); }
+    else if constexpr (I == 19) s.zx = acx_sub_hi_half(s.qx, hi, false);
+    else if constexpr (I == 20) s.zy = acx_sub_hi_half(s.qy, hi, true);
+    else { f32x2 r; r.x = s.zx; r.y = s.zy; lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2)); }
+}
+// the whole pair at once (epilogues: nothing to interleave with)
+__device__ __forceinline__ void gelu3_pair(const GeluK3 k, const float ax, const float ay, unsigned& hi, unsigned& lo) {
+    GeluState3 s;
+    gelu3_nano<0>(s, k, ax, ay, hi, lo); gelu3_nano<1>(s, k, ax, ay, hi, lo); gelu3_nano<2>(s, k, ax, ay, hi, lo);
+    gelu3_nano<3>(s, k, ax, ay, hi, lo); gelu3_nano<4>(s, k, ax, ay, hi, lo); gelu3_nano<5>(s, k, ax, ay, hi, lo);
+    gelu3_nano<6>(s, k, ax, ay, hi, lo); gelu3_nano<7>(s, k, ax, ay, hi, lo); gelu3_nano<8>(s, k, ax, ay, hi, lo);
+    gelu3_nano<9>(s, k, ax, ay, hi, lo); gelu3_nano<10>(s, k, ax, ay, hi, lo); gelu3_nano<11>(s, k, ax, ay, hi, lo);
+    gelu3_nano<12>(s, k, ax, ay, hi, lo); gelu3_nano<13>(s, k, ax, ay, hi, lo); gelu3_nano<14>(s, k, ax, ay, hi, lo);
+    gelu3_nano<15>(s, k, ax, ay, hi, lo); gelu3_nano<16>(s, k, ax, ay, hi, lo); gelu3_nano<17>(s, k, ax, ay, hi, lo);
+    gelu3_nano<18>(s, k, ax, ay, hi, lo); gelu3_nano<19>(s, k, ax, ay, hi, lo); gelu3_nano<20>(s, k, ax, ay, hi, lo);
+    gelu3_nano<21>(s, k, ax, ay, hi, lo);
+}
+
 // The same GELU + split as THIRTY single-instruction steps per register pair ("nano-steps"), for kernels that place
 // every filler of an MFMA gap by count: at one wave per SIMD up to five single-issue instructions per v_mfma_f32_32x32x16
 // gap are free and each further one costs ~5 cycles (profiles/r03_a_coissue_table.txt), so what matters is that NO gap
