@@ -9,6 +9,7 @@
 // fragment read is still one ds_read_b128: lane half h takes chunk 2g+h of its row = k 16g+8h .. +7, exactly
 // the A/B lane map of the 32x32x16 instruction, so one MFMA per (tile, k-group) replaces four fp32 ones.
 #include "acx_internal.h"
+#include "split_math.h"
 
 namespace acx {
 
@@ -19,17 +20,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kBfRowBytes = 128;        // 64 bf16 per LDS row
 constexpr int kBfBK = 64;
 
-__device__ __forceinline__ float gelu_erf_b(float v) {     // see gemm.hip
-    const float av = fabsf(v);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678f, av, 1.0f));
-    float pl = fmaf(1.061405429f, t, -1.453152027f);
-    pl = fmaf(pl, t, 1.421413741f);
-    pl = fmaf(pl, t, -0.284496736f);
-    pl = fmaf(pl, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(v * v * -0.72134752f);
-    const float q = pl * t * e;
-    return fmaf(-0.5f * av, q, fmaxf(v, 0.0f));
-}
+__device__ __forceinline__ float gelu_erf_b(float v) { return gelu3_unit(v); }     // split_math.h, third form
 
 struct GemmBfParams {
     const __bf16* A; const __bf16* Wt; const float* bias; void* out; const float* resid;

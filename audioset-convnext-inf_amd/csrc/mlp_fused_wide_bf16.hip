@@ -157,11 +157,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     for (int q = 0; q < kVar1; ++q) w1off[q] = l31 * (2 * C) + (((2 * q + hh) ^ Cfg::swz1(l31)) << 4);
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp) w2off[sp] = l31 * 128 + (((2 * sp + hh) ^ ((l31 >> 1) & 7)) << 4);
-    GeluConsts gk;                // X holds the pre-activation itself (no operand scales in this arithmetic)
-    gk.ps = 0.3275911f * 0.70710678f;
-    gk.cq = 0.84932180f;
-    gk.ca = -0.5f;
-    gk.cb = 1.0f;             // (gelu_micro<., UNIT = true> does not use them)
+    const GeluK3 gk = gelu_k3(1.0f, 1.0f);      // X holds the pre-activation itself (no operand scales in this arithmetic): z = 0.5 v
 
 #define ACX_B8(v_) __builtin_bit_cast(bf16x8, v_)
 #define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
@@ -185,15 +181,15 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
 #define ACX_MICRO_RANGE(half_, from_, to_)                                                                      \
         _Pragma("unroll") for (int sg_ = (from_); sg_ < (to_); ++sg_) {                                         \
             const int mt_ = sg_ / 64, pr_ = (sg_ % 64) / 8, st_ = sg_ % 8;                                      \
-            unsigned dummy_;                                                                                    \
-            if (st_ == 0) { gs.ax = Xv[mt_][half_][2 * pr_]; gs.ay = Xv[mt_][half_][2 * pr_ + 1]; gelu_micro<0, true>(gs, gk, dummy_, dummy_); } \
-            else if (st_ == 1) gelu_micro<1, true>(gs, gk, dummy_, dummy_);                                           \
-            else if (st_ == 2) gelu_micro<2, true>(gs, gk, dummy_, dummy_);                                           \
-            else if (st_ == 3) gelu_micro<3, true>(gs, gk, dummy_, dummy_);                                           \
-            else if (st_ == 4) gelu_micro<4, true>(gs, gk, dummy_, dummy_);                                           \
-            else if (st_ == 5) gelu_micro<5, true>(gs, gk, dummy_, dummy_);                                           \
-            else if (st_ == 6) gelu_micro<6, true>(gs, gk, dummy_, dummy_);                                           \
-            else un[mt_][half_][pr_] = pack_bf16(gs.gx, gs.gy);                                                 \
+            const float ax_ = Xv[mt_][half_][2 * pr_], ay_ = Xv[mt_][half_][2 * pr_ + 1];                       \
+            if (st_ == 0) gelu3_micro<0>(gs, gk, ax_, ay_);                                                     \
+            else if (st_ == 1) gelu3_micro<1>(gs, gk, ax_, ay_);                                                \
+            else if (st_ == 2) gelu3_micro<2>(gs, gk, ax_, ay_);                                                \
+            else if (st_ == 3) gelu3_micro<3>(gs, gk, ax_, ay_);                                                \
+            else if (st_ == 4) gelu3_micro<4>(gs, gk, ax_, ay_);                                                \
+            else if (st_ == 5) gelu3_micro<5>(gs, gk, ax_, ay_);                                                \
+            else if (st_ == 6) gelu3_micro<6>(gs, gk, ax_, ay_);                                                \
+            else un[mt_][half_][pr_] = pack_bf16(gs.qx, gs.qy);                                                 \
         }
 #define ACX_TOUCH1(f_) { asm volatile("" :: "v"(f_)); }
     // Xn[.][j] starts from the bias of hidden units 64 k + 32 j + (lane layout of a 32 x 32 accumulator)
@@ -221,7 +217,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     f32x4 g[PT][4];               // G(k - 1): B operand of phase 2, four k-steps of 8 bf16
     unsigned un[PT][2][8];        // G(k) under construction
     constexpr int kDmaStride = Cfg::kUnits / Cfg::kPieces;
-    GeluState gs;
+    GeluState3 gs;
 
     auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
         constexpr bool HV = decltype(with_gelu)::value;     // second half (X tile 1) of the GELU of Xv rides on this segment's MFMAs
@@ -459,11 +455,7 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
     for (int q = 0; q < kVar1; ++q) w1off[q] = l31 * (2 * C) + (((2 * q + hh) ^ Cfg::swz1(l31)) << 4);
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp) w2off[sp] = l31 * 128 + (((2 * sp + hh) ^ ((l31 >> 1) & 7)) << 4);
-    GeluConsts gk;
-    gk.ps = 0.3275911f * 0.70710678f;
-    gk.cq = 0.84932180f;
-    gk.ca = -0.5f;
-    gk.cb = 1.0f;             // (gelu_micro<., UNIT = true> does not use them)
+    const GeluK3 gk = gelu_k3(1.0f, 1.0f);      // X holds the pre-activation itself (no operand scales in this arithmetic): z = 0.5 v
 #define ACX_B8(v_) __builtin_bit_cast(bf16x8, v_)
 #define ACX_W1_RD(base_, u_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) & 1) * (32 * 2 * C) + (((u_) >> 1) / kVar1) * (kVar1 * 32) + w1off[((u_) >> 1) % kVar1]))
 #define ACX_W2_RD(base_, u_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) >> 2) * 4096 + w2off[(u_) & 3]))
@@ -560,13 +552,11 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
                 unsigned un[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    GeluState gs;
-                    unsigned dummy;
-                    gs.ax = X[sp >> 1][2 * (4 * (sp & 1) + p)]; gs.ay = X[sp >> 1][2 * (4 * (sp & 1) + p) + 1];
-                    gelu_micro<0, true>(gs, gk, dummy, dummy); gelu_micro<1, true>(gs, gk, dummy, dummy); gelu_micro<2, true>(gs, gk, dummy, dummy);
-                    gelu_micro<3, true>(gs, gk, dummy, dummy); gelu_micro<4, true>(gs, gk, dummy, dummy); gelu_micro<5, true>(gs, gk, dummy, dummy);
-                    gelu_micro<6, true>(gs, gk, dummy, dummy);
-                    un[p] = pack_bf16(gs.gx, gs.gy);
+                    GeluState3 gs;
+                    const float ax = X[sp >> 1][2 * (4 * (sp & 1) + p)], ay = X[sp >> 1][2 * (4 * (sp & 1) + p) + 1];
+                    gelu3_micro<0>(gs, gk, ax, ay); gelu3_micro<1>(gs, gk, ax, ay); gelu3_micro<2>(gs, gk, ax, ay); gelu3_micro<3>(gs, gk, ax, ay);
+                    gelu3_micro<4>(gs, gk, ax, ay); gelu3_micro<5>(gs, gk, ax, ay); gelu3_micro<6>(gs, gk, ax, ay);
+                    un[p] = pack_bf16(gs.qx, gs.qy);
                 }
                 g[sp] = __builtin_bit_cast(f32x4, uint4{un[0], un[1], un[2], un[3]});
             }

@@ -281,6 +281,35 @@ __device__ __forceinline__ void gelu3_pair(const GeluK3 k, const float ax, const
     gelu3_nano<21>(s, k, ax, ay, hi, lo);
 }
 
+// The third form in SEVEN micro-steps of 2-4 instructions for a register pair, result left in (s.qx, s.qy) -- the bf16 kernels
+// (two pixel tiles or two waves per SIMD: a micro-step per MFMA; no hi / lo split, the caller packs to bf16).  With
+// k = gelu_k3(1, 1) the unit is z = 0.5 v and the result gelu(v) itself.
+template <int STEP>
+__device__ __forceinline__ void gelu3_micro(GeluState3& s, const GeluK3 k, const float ax, const float ay) {
+    if constexpr (STEP == 0) { s.zx = ax * k.zs; s.zy = ay * k.zs; }
+    else if constexpr (STEP == 1) { s.qx = __builtin_fmaf(__builtin_fabsf(s.zx), k.k4, k.k3); s.qy = __builtin_fmaf(__builtin_fabsf(s.zy), k.k4, k.k3); }
+    else if constexpr (STEP == 2) { s.qx = __builtin_fmaf(s.qx, __builtin_fabsf(s.zx), k.k2); s.qy = __builtin_fmaf(s.qy, __builtin_fabsf(s.zy), k.k2); }
+    else if constexpr (STEP == 3) { s.qx = __builtin_fmaf(s.qx, __builtin_fabsf(s.zx), k.k1); s.qy = __builtin_fmaf(s.qy, __builtin_fabsf(s.zy), k.k1); }
+    else if constexpr (STEP == 4) { s.qx = __builtin_fmaf(s.qx, __builtin_fabsf(s.zx), k.k0); s.qy = __builtin_fmaf(s.qy, __builtin_fabsf(s.zy), k.k0); }
+    else if constexpr (STEP == 5) {
+        s.qx *= __builtin_fabsf(s.zx); s.qy *= __builtin_fabsf(s.zy);
+        s.qx = __builtin_amdgcn_exp2f(s.qx); s.qy = __builtin_amdgcn_exp2f(s.qy);
+    } else {
+        s.qx = 1.0f - s.qx; s.qy = 1.0f - s.qy;
+        s.qx = __builtin_fmaf(__builtin_fabsf(s.zx), s.qx, s.zx); s.qy = __builtin_fmaf(__builtin_fabsf(s.zy), s.qy, s.zy);
+    }
+}
+// one value, all at once (epilogues of the bf16 GEMMs)
+__device__ __forceinline__ float gelu3_unit(const float v) {
+    const float z = 0.5f * v, a = __builtin_fabsf(z);
+    float q = __builtin_fmaf(a, -0.0004882981302216649f * 32.0f, 0.00719997426494956f * 16.0f);
+    q = __builtin_fmaf(q, a, -0.05214935168623924f * 8.0f);
+    q = __builtin_fmaf(q, a, -0.4595935642719269f * 4.0f);
+    q = __builtin_fmaf(q, a, -1.1510010957717896f * 2.0f);
+    const float e = __builtin_amdgcn_exp2f(q * a);
+    return __builtin_fmaf(a, 1.0f - e, z);
+}
+
 // The same GELU + split as THIRTY single-instruction steps per register pair ("nano-steps"), for kernels that place
 // every filler of an MFMA gap by count: at one wave per SIMD up to five single-issue instructions per v_mfma_f32_32x32x16
 // gap are free and each further one costs ~5 cycles (profiles/r03_a_coissue_table.txt), so what matters is that NO gap
