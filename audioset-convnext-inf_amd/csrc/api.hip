@@ -134,8 +134,8 @@ static float s16_scale(const std::vector<float>& w) {
 
 // Power-of-two scale of the S16 hidden activation of one block.  The GEMM input is z = LayerNorm(y) without affine
 // (the affine is folded into w1 / b1): ||z||_2 <= sqrt(C), so |h_n| = |w1_n . z + b1_n| <= ||w1_n||_2 sqrt(C) + |b1_n|
-// (Cauchy-Schwarz) and |GELU(h)| <= |h|.  The scale puts that bound below the largest fp16 number: the clamp in
-// gelu_piece3 (split_math.h) cannot be reached, whatever the input.  Typical weights give 2^10..2^11; the absolute
+// (Cauchy-Schwarz) and |GELU(h)| <= |h|.  The scale puts that bound below the largest fp16 number: the GELU's
+// fp32 -> fp16 conversion (split_math.h) cannot overflow, whatever the input (bounded below at 2^-24 -- weights of ~1e11).  Typical weights give 2^10..2^11; the absolute
 // resolution of a stored value is 2^-25 / scale (fp16 subnormal spacing of the lo half).
 static float hidden_scale_for(const std::vector<float>& w1, const std::vector<float>& b1, int N, int C) {
     double worst = 0.0;

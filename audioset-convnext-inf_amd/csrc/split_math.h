@@ -1,5 +1,4 @@
-// Shared by the split-fp16 kernels (gemm_split.hip, mlp_fused_split.hip): vector types, the packed-fp32 GELU and
-// the fp32 -> (fp16 hi, fp16 lo) split.
+// Shared by the split-fp16 and bf16 kernels: vector types, LDS-DMA helpers, the GELU and the fp32 -> (fp16 hi, fp16 lo) split.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -10,93 +9,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 bc2(float v) { f32x2 r; r.x = v; r.y = v; return r; }
-
-// v = a * s;  g = gelu_erf(v) * kH (A&S 7.1.26, see gemm.hip) for two values, in three pieces; the result comes
-// back as packed fp16 hi / lo halves
-struct GeluConsts { float ps, cq, ca, cb; };
-__device__ __forceinline__ void gelu_piece1(f32x2 a, const GeluConsts k, f32x2& av, f32x2& t, f32x2& e) {
-    av.x = __builtin_fabsf(a.x); av.y = __builtin_fabsf(a.y);
-    const f32x2 den = fma2(av, bc2(k.ps), bc2(1.0f));
-    t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
-    const f32x2 u = a * bc2(k.cq);                  // scaled first: a * a alone may overflow for very small weights
-    const f32x2 ex = -(u * u);
-    e.x = __builtin_amdgcn_exp2f(ex.x); e.y = __builtin_amdgcn_exp2f(ex.y);
-}
-__device__ __forceinline__ void gelu_piece2(f32x2 a, f32x2 av, f32x2 t, f32x2 e, const GeluConsts k, f32x2& g) {
-    f32x2 pl = fma2(t, bc2(1.061405429f), bc2(-1.453152027f));
-    pl = fma2(pl, t, bc2(1.421413741f));
-    pl = fma2(pl, t, bc2(-0.284496736f));
-    pl = fma2(pl, t, bc2(0.254829592f));
-    const f32x2 q = pl * t * e;
-    f32x2 pos = a * bc2(k.cb);
-    pos.x = __builtin_fmaxf(pos.x, 0.f); pos.y = __builtin_fmaxf(pos.y, 0.f);
-    g = fma2(av * bc2(k.ca), q, pos);
-}
-__device__ __forceinline__ void gelu_piece3(f32x2 g, unsigned& hi, unsigned& lo) {
-    g.x = __builtin_fminf(g.x, 65504.f); g.y = __builtin_fminf(g.y, 65504.f);
-    const h2 h = __builtin_convertvector(g, h2);
-    const f32x2 back = __builtin_convertvector(h, f32x2);
-    const h2 l = __builtin_convertvector(g - back, h2);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
-
-// The same GELU + split as NINE micro-steps of 4-6 vector instructions each (mlp_fused_wide.hip: one wave per SIMD issues
-// both the matrix and the vector stream, so the vector work is cut fine enough to sit in the issue shadow of single
-// MFMAs: ~24 cycles of vector issue hide behind a 32-cycle MFMA).  One register pair of the accumulator = two values;
-// the state of a pair lives across its steps.  Written on SCALAR floats and compiled with -fno-slp-vectorize: beside
-// MFMAs a packed-FP32 instruction costs far more than the two scalar ones it replaces (MI355X_MICROARCH.md, cycle
-// constants: "1 v_pk_fma_f32 +22 cycles vs 2 v_fma_f32").  |a| is written as fabs at each use so that it folds into
-// the consuming instruction's source modifier.
-struct GeluState { float ax, ay, tx, ty, ex, ey, px, py, gx, gy; };
-// The polynomial carries the factor -0.5 of  gelu = max(v, 0) - 0.5 |v| q  in its coefficients (exact: a power of two), and
-// |v| kH = |a cb| is taken from the scaled value the positive part needs anyway.  UNIT: cb == 1 (bf16 arithmetic: the
-// accumulator holds v itself), the scaling multiply disappears.
-template <int STEP, bool UNIT = false>
-__device__ __forceinline__ void gelu_micro(GeluState& s, const GeluConsts k, unsigned& hi, unsigned& lo) {
-    if constexpr (STEP == 0) {
-        s.tx = __builtin_fmaf(__builtin_fabsf(s.ax), k.ps, 1.0f);                 // den
-        s.ty = __builtin_fmaf(__builtin_fabsf(s.ay), k.ps, 1.0f);
-    } else if constexpr (STEP == 1) {
-        s.tx = __builtin_amdgcn_rcpf(s.tx); s.ty = __builtin_amdgcn_rcpf(s.ty);
-        s.ex = s.ax * k.cq; s.ey = s.ay * k.cq;                                   // u (scaled first: a * a alone may overflow)
-    } else if constexpr (STEP == 2) {
-        s.ex = __builtin_amdgcn_exp2f(-(s.ex * s.ex)); s.ey = __builtin_amdgcn_exp2f(-(s.ey * s.ey));
-    } else if constexpr (STEP == 3) {
-        s.px = __builtin_fmaf(s.tx, -0.5f * 1.061405429f, -0.5f * -1.453152027f); s.py = __builtin_fmaf(s.ty, -0.5f * 1.061405429f, -0.5f * -1.453152027f);
-        s.px = __builtin_fmaf(s.px, s.tx, -0.5f * 1.421413741f); s.py = __builtin_fmaf(s.py, s.ty, -0.5f * 1.421413741f);
-    } else if constexpr (STEP == 4) {
-        s.px = __builtin_fmaf(s.px, s.tx, -0.5f * -0.284496736f); s.py = __builtin_fmaf(s.py, s.ty, -0.5f * -0.284496736f);
-        s.px = __builtin_fmaf(s.px, s.tx, -0.5f * 0.254829592f); s.py = __builtin_fmaf(s.py, s.ty, -0.5f * 0.254829592f);
-        s.px *= s.tx; s.py *= s.ty;
-    } else if constexpr (STEP == 5) {
-        s.px *= s.ex; s.py *= s.ey;                                               // -0.5 q
-        if constexpr (!UNIT) { s.gx = s.ax * k.cb; s.gy = s.ay * k.cb; }          // v kH
-    } else if constexpr (STEP == 6) {
-        // no clamp to the fp16 range: acx_finalize bounds |h| and picks the hidden scale so that it cannot be exceeded
-        // (api.hip, hidden_scale_for); were it ever exceeded the result would be inf / NaN -- loud, not silently saturated
-        if constexpr (UNIT) {
-            s.gx = __builtin_fmaf(__builtin_fabsf(s.ax), s.px, __builtin_fmaxf(s.ax, 0.f));
-            s.gy = __builtin_fmaf(__builtin_fabsf(s.ay), s.py, __builtin_fmaxf(s.ay, 0.f));
-        } else {
-            s.gx = __builtin_fmaf(__builtin_fabsf(s.gx), s.px, __builtin_fmaxf(s.gx, 0.f));
-            s.gy = __builtin_fmaf(__builtin_fabsf(s.gy), s.py, __builtin_fmaxf(s.gy, 0.f));
-        }
-    } else if constexpr (STEP == 7) {
-        f32x2 g; g.x = s.gx; g.y = s.gy;
-        const h2 h = __builtin_convertvector(g, h2);
-        hi = __builtin_bit_cast(unsigned, h);
-        s.tx = (float)h.x; s.ty = (float)h.y;                                     // back
-    } else {
-        f32x2 r; r.x = s.gx - s.tx; r.y = s.gy - s.ty;
-        const h2 l = __builtin_convertvector(r, h2);
-        lo = __builtin_bit_cast(unsigned, l);
-    }
-}
-
 
 // One 1-KB LDS-DMA piece (global_load_lds_dwordx4: lane l's 16 bytes from gsrc land at lds_dst + 16 l) issued from inline
 // asm, so that hipcc does NOT know an LDS write is in flight: next to the builtin form it orders the next LDS read of the
@@ -144,77 +56,21 @@ __device__ __forceinline__ unsigned acx_lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(p);
 }
 
-// ---- GELU + split, second form (round 3): 15 vector instructions per element instead of 17-19 -------------------------
-//   gelu(v) kH = 0.5 kH v + |v| kH (0.5 - 0.5 q(|v|)),   q = erfc(|v| / sqrt 2) = poly(t) t exp(-v^2 / 2)   (A&S 7.1.26)
-// With a = v / sinv (the accumulator's unit) and hb = 0.5 sinv kH:   g = fma(|a|, r, a hb),   r = fma(P, e, hb),
-// P = t (K1' + t (K2' + ...)),  K' = -hb K  -- the factors -0.5, sinv and kH ride in the polynomial's coefficients (five
-// scalars per launch), the positive part costs no v_max, and the fp32 -> fp16 hi / lo split is v_cvt_pk_f16_f32 +
-// v_fma_mix_f32 (g - float(hi) in ONE instruction per element, straight from the packed hi halves) + v_cvt_pk_f16_f32.
-// For v << 0 the two terms cancel: exactly when q has underflowed (r == hb), and otherwise with an absolute error of
-// |v| kH 2^-25 -- what the reference's own fp32 evaluation of 0.5 v (1 + erf) carries there.
-// EIGHT micro-steps of 2-6 instructions per register pair (two values); the state of a pair lives across its steps.
-struct GeluK2 { float ps, cq, hb, k1, k2, k3, k4, k5; };
-__device__ __forceinline__ GeluK2 gelu_k2(float sinv, float kh) {
-    GeluK2 k;
-    k.ps = 0.3275911f * 0.70710678f * sinv;
-    k.cq = 0.84932180f * sinv;          // sqrt(log2(e) / 2): exp(-v^2 / 2) = exp2(-(cq a)^2)
-    k.hb = 0.5f * sinv * kh;            // a power of two times 0.5: the products below are exact scalings
-    k.k1 = -k.hb * 0.254829592f; k.k2 = -k.hb * -0.284496736f; k.k3 = -k.hb * 1.421413741f;
-    k.k4 = -k.hb * -1.453152027f; k.k5 = -k.hb * 1.061405429f;
-    return k;
-}
-// Two waves per SIMD (mlp_fused_split.hip): a VALU instruction with a scalar-register operand issues at 4.2 cycles, the
-// same instruction on vector registers only at 2.2 (profiles/r03_c_valu_opcode_costs.txt) -- pin the eight constants in
-// VGPRs there.  At one wave per SIMD both forms cost the same; the wide kernels keep them scalar.
-__device__ __forceinline__ void gelu_k2_to_vgprs(GeluK2& k) {
-    asm volatile("" : "+v"(k.ps), "+v"(k.cq), "+v"(k.hb), "+v"(k.k1), "+v"(k.k2), "+v"(k.k3), "+v"(k.k4), "+v"(k.k5));
-}
-struct GeluState2 { float ax, ay, tx, ty, ex, ey, px, py; };
-__device__ __forceinline__ float acx_sub_hi_half(float g, unsigned h, const bool upper) {      // g - float(half of h)
+// g - float(one fp16 half of h) in ONE instruction (v_fma_mix_f32 reads the half straight from the packed register)
+__device__ __forceinline__ float acx_sub_hi_half(float g, unsigned h, const bool upper) {
     float r;
     if (upper) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(g), "v"(h));
     else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(g), "v"(h));
     return r;
 }
-template <int STEP>
-__device__ __forceinline__ void gelu_micro2(GeluState2& s, const GeluK2 k, unsigned& hi, unsigned& lo) {
-    if constexpr (STEP == 0) {
-        s.tx = __builtin_fmaf(__builtin_fabsf(s.ax), k.ps, 1.0f);                 // den
-        s.ty = __builtin_fmaf(__builtin_fabsf(s.ay), k.ps, 1.0f);
-    } else if constexpr (STEP == 1) {
-        s.tx = __builtin_amdgcn_rcpf(s.tx); s.ty = __builtin_amdgcn_rcpf(s.ty);
-        s.ex = s.ax * k.cq; s.ey = s.ay * k.cq;                                   // u (scaled first: a * a alone may overflow)
-    } else if constexpr (STEP == 2) {
-        s.ex = __builtin_amdgcn_exp2f(-(s.ex * s.ex)); s.ey = __builtin_amdgcn_exp2f(-(s.ey * s.ey));
-    } else if constexpr (STEP == 3) {
-        s.px = __builtin_fmaf(s.tx, k.k5, k.k4); s.py = __builtin_fmaf(s.ty, k.k5, k.k4);
-        s.px = __builtin_fmaf(s.px, s.tx, k.k3); s.py = __builtin_fmaf(s.py, s.ty, k.k3);
-    } else if constexpr (STEP == 4) {
-        s.px = __builtin_fmaf(s.px, s.tx, k.k2); s.py = __builtin_fmaf(s.py, s.ty, k.k2);
-        s.px = __builtin_fmaf(s.px, s.tx, k.k1); s.py = __builtin_fmaf(s.py, s.ty, k.k1);
-        s.px *= s.tx; s.py *= s.ty;                                               // -hb poly(t) t
-    } else if constexpr (STEP == 5) {
-        s.px = __builtin_fmaf(s.px, s.ex, k.hb); s.py = __builtin_fmaf(s.py, s.ey, k.hb);     // r = hb (1 - q)
-        s.tx = s.ax * k.hb; s.ty = s.ay * k.hb;                                   // 0.5 v kH
-    } else if constexpr (STEP == 6) {
-        // no clamp to the fp16 range: acx_finalize bounds |h| and picks the hidden scale so that it cannot be exceeded
-        // (api.hip, hidden_scale_for); were it ever exceeded the result would be inf / NaN -- loud, not silently saturated
-        s.ex = __builtin_fmaf(__builtin_fabsf(s.ax), s.px, s.tx);                 // g
-        s.ey = __builtin_fmaf(__builtin_fabsf(s.ay), s.py, s.ty);
-        f32x2 g; g.x = s.ex; g.y = s.ey;
-        hi = __builtin_bit_cast(unsigned, __builtin_convertvector(g, h2));
-    } else {
-        f32x2 r; r.x = acx_sub_hi_half(s.ex, hi, false); r.y = acx_sub_hi_half(s.ey, hi, true);
-        lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
-    }
-}
 
-// ---- GELU + split, third form (round 3): 11 vector instructions per element, ONE transcendental --------------------------
+// ---- GELU + split (third form, round 3; rounds 1-2: A&S 7.1.26 in 17-19 packed, then 15 scalar instructions per element -- git
+// history): 11 vector instructions per element, ONE transcendental --------------------------
 //   erfc(|v| / sqrt 2) ~= E(|v|) = exp2(-|v| Q(|v|)),  Q of degree 4 (five coefficients, leading one positive: -|v| Q -> -inf
 //   for large |v|, E -> 0 without a clamp; E(0) = 1 exactly, so the relative accuracy near 0 is kept)
 //   gelu(v) = 0.5 v + 0.5 |v| (1 - E):  minimax fit of 0.5 |v| (E - erfc) over [0, 9] (tools/lab/fit_gelu.py):
 //   |gelu error| <= 5.4e-7 in exact arithmetic, <= 1e-6 as evaluated in fp32 (the fp32 rounding of a result near 4 is
-//   4.8e-7), against 2.1e-7 for A&S 7.1.26 above -- whose 1 / (1 + p |v|) and exp(-v^2 / 2) cost a second transcendental
+//   4.8e-7), against 2.1e-7 for A&S 7.1.26 (the native-fp32 path, gemm.hip) -- whose 1 / (1 + p |v|) and exp(-v^2 / 2) cost a second transcendental
 //   (8 issue cycles each against 2-4 for an FMA, profiles/r03_c_valu_opcode_costs.txt) and four more instructions.
 // Unit: z = a (sinv 0.5 kH) = 0.5 kH v, the linear term of the result itself (one exact power-of-two multiply):
 //   g = gelu(v) kH = z + |z| (1 - E),   exp2 argument = |z| (K0 + K1 |z| + ... + K4 |z|^4),  Kj = -cj / (0.5 kH)^(j+1)
@@ -236,7 +92,9 @@ __device__ __forceinline__ GeluK3 gelu_k3(float sinv, float kh) {
     k.k4 = -0.0004882981302216649f * s;
     return k;
 }
-// two waves per SIMD: constants in VGPRs (see gelu_k2_to_vgprs)
+// Two waves per SIMD (mlp_fused_split.hip): a VALU instruction with a scalar-register operand issues at 4.2 cycles, the same
+// instruction on vector registers only at 2.2 (profiles/r03_c_valu_opcode_costs.txt) -- pin the constants in VGPRs there.  At one
+// wave per SIMD both forms cost the same; the wide kernels keep them scalar.
 __device__ __forceinline__ void gelu_k3_to_vgprs(GeluK3& k) {
     asm volatile("" : "+v"(k.zs), "+v"(k.k0), "+v"(k.k1), "+v"(k.k2), "+v"(k.k3), "+v"(k.k4));
 }
@@ -309,45 +167,5 @@ __device__ __forceinline__ float gelu3_unit(const float v) {
     const float e = __builtin_amdgcn_exp2f(q * a);
     return __builtin_fmaf(a, 1.0f - e, z);
 }
-
-// The same GELU + split as THIRTY single-instruction steps per register pair ("nano-steps"), for kernels that place
-// every filler of an MFMA gap by count: at one wave per SIMD up to five single-issue instructions per v_mfma_f32_32x32x16
-// gap are free and each further one costs ~5 cycles (profiles/r03_a_coissue_table.txt), so what matters is that NO gap
-// carries more than its budget -- the eight micro-steps above (2-6 instructions each, next to a gap's fragment reads, wait and
-// LDS-DMA piece) left gaps of 9-13 fillers beside bursts of bare MFMAs.  Same arithmetic, same order, same rounding.
-template <int I>
-__device__ __forceinline__ void gelu_nano(GeluState2& s, const GeluK2 k, unsigned& hi, unsigned& lo) {
-    if constexpr (I == 0) s.tx = __builtin_fmaf(__builtin_fabsf(s.ax), k.ps, 1.0f);
-    else if constexpr (I == 1) s.ty = __builtin_fmaf(__builtin_fabsf(s.ay), k.ps, 1.0f);
-    else if constexpr (I == 2) s.tx = __builtin_amdgcn_rcpf(s.tx);
-    else if constexpr (I == 3) s.ty = __builtin_amdgcn_rcpf(s.ty);
-    else if constexpr (I == 4) s.ex = s.ax * k.cq;
-    else if constexpr (I == 5) s.ey = s.ay * k.cq;
-    else if constexpr (I == 6) s.ex = -(s.ex * s.ex);
-    else if constexpr (I == 7) s.ex = __builtin_amdgcn_exp2f(s.ex);
-    else if constexpr (I == 8) s.ey = -(s.ey * s.ey);
-    else if constexpr (I == 9) s.ey = __builtin_amdgcn_exp2f(s.ey);
-    else if constexpr (I == 10) s.px = __builtin_fmaf(s.tx, k.k5, k.k4);
-    else if constexpr (I == 11) s.py = __builtin_fmaf(s.ty, k.k5, k.k4);
-    else if constexpr (I == 12) s.px = __builtin_fmaf(s.px, s.tx, k.k3);
-    else if constexpr (I == 13) s.py = __builtin_fmaf(s.py, s.ty, k.k3);
-    else if constexpr (I == 14) s.px = __builtin_fmaf(s.px, s.tx, k.k2);
-    else if constexpr (I == 15) s.py = __builtin_fmaf(s.py, s.ty, k.k2);
-    else if constexpr (I == 16) s.px = __builtin_fmaf(s.px, s.tx, k.k1);
-    else if constexpr (I == 17) s.py = __builtin_fmaf(s.py, s.ty, k.k1);
-    else if constexpr (I == 18) s.px *= s.tx;
-    else if constexpr (I == 19) s.py *= s.ty;
-    else if constexpr (I == 20) s.px = __builtin_fmaf(s.px, s.ex, k.hb);
-    else if constexpr (I == 21) s.py = __builtin_fmaf(s.py, s.ey, k.hb);
-    else if constexpr (I == 22) s.tx = s.ax * k.hb;
-    else if constexpr (I == 23) s.ty = s.ay * k.hb;
-    else if constexpr (I == 24) s.ex = __builtin_fmaf(__builtin_fabsf(s.ax), s.px, s.tx);
-    else if constexpr (I == 25) s.ey = __builtin_fmaf(__builtin_fabsf(s.ay), s.py, s.ty);
-    else if constexpr (I == 26) { f32x2 g; g.x = s.ex; g.y = s.ey; hi = __builtin_bit_cast(unsigned, __builtin_convertvector(g, h2)); }
-    else if constexpr (I == 27) s.px = acx_sub_hi_half(s.ex, hi, false);
-    else if constexpr (I == 28) s.py = acx_sub_hi_half(s.ey, hi, true);
-    else { f32x2 r; r.x = s.px; r.y = s.py; lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2)); }
-}
-constexpr int kGeluNano = 30;       // nano-steps per register pair
 
 }  // namespace acx

@@ -15,7 +15,7 @@ variant() {   # name, sed expressions...
   sed -i 's#"acx_internal.h"#"'$S'/acx_internal.h"#; s#"split_math.h"#"'$S'/split_math.h"#' $f
   hipcc -O3 -std=c++17 -fno-slp-vectorize --offload-arch=gfx950 -w $EXTRA -DWIDE_C=$C -DWIDE_BF16=$ABF -DWIDE_SRC="\"$PWD/$f\"" tools/wide_lab.hip -o $O/ablb${C}_${ABF}_$name &
 }
-NOGELU='s/gelu_micro<[0-9], true>\(gs, gk, dummy_?, dummy_?\);?/;/g; s/pack_bf16\(gs\.gx, gs\.gy\)/pack_bf16(gs.ax, gs.ay)/'
+NOGELU='s/gelu3_micro<[0-9]>\(gs, gk, ax_?, ay_?\);?/;/g; s/pack_bf16\(gs\.qx, gs\.qy\)/pack_bf16(ax_, ay_)/'
 NOMFMA='s/__builtin_amdgcn_mfma_f32_32x32x16_bf16\(/acx_fake_mfma(/; s/^namespace acx \{$/namespace acx { typedef float f32x16_ __attribute__((ext_vector_type(16))); template <class A, class B> __device__ __forceinline__ f32x16_ acx_fake_mfma(A a, B b, f32x16_ c, int, int, int) { asm volatile("" :: "v"(a), "v"(b)); return c; }/'
 NODSREAD='s/^#define ACX_W1_RD\(base_, u_\).*/#define ACX_W1_RD(base_, u_) (ACX_ACT0[(u_) % 4])/; s/^#define ACX_W2_RD\(base_, u_\).*/#define ACX_W2_RD(base_, u_) (ACX_ACT0[((u_) + 1) % 4])/'
 variant full
