@@ -73,20 +73,32 @@ __global__ __launch_bounds__(768) void pool_head_kernel(const float* __restrict_
     float4 e[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) e[k] = *reinterpret_cast<const float4*>(&emb[4 * (lane + 64 * k)]);
-    for (int n = wave; n < kClasses; n += 12) {
-        const float4* wr = reinterpret_cast<const float4*>(hw + (long long)n * 768);
-        float s = 0.f;
+    // four rows of the head per wave and pass: 12 independent 16-byte loads per lane in flight (one row at a time was a chain
+    // of 44 L2 round trips per wave)
+    for (int n0 = wave; n0 < kClasses; n0 += 48) {
+        float4 w4[4][3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float4 w4 = wr[lane + 64 * k];
-            s = fmaf(e[k].x, w4.x, s); s = fmaf(e[k].y, w4.y, s);
-            s = fmaf(e[k].z, w4.z, s); s = fmaf(e[k].w, w4.w, s);
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 12 * r < kClasses ? n0 + 12 * r : n0;
+            const float4* wr = reinterpret_cast<const float4*>(hw + (long long)n * 768);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w4[r][k] = wr[lane + 64 * k];
         }
-        s = wave_sum(s);
-        if (lane == 0) {
-            const float z = s + hb[n];
-            if (logits) logits[b * kClasses + n] = z;
-            if (probs) probs[b * kClasses + n] = 1.0f / (1.0f + expf(-z));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s = fmaf(e[k].x, w4[r][k].x, s); s = fmaf(e[k].y, w4[r][k].y, s);
+                s = fmaf(e[k].z, w4[r][k].z, s); s = fmaf(e[k].w, w4[r][k].w, s);
+            }
+            s = wave_sum(s);
+            const int n = n0 + 12 * r;
+            if (lane == 0 && n < kClasses) {
+                const float z = s + hb[n];
+                if (logits) logits[b * kClasses + n] = z;
+                if (probs) probs[b * kClasses + n] = 1.0f / (1.0f + expf(-z));
+            }
         }
     }
 }
