@@ -57,3 +57,55 @@ def test_three_term_product_matches_fp32_matmul_error(K, act_scale):
     # dropping the lo halves altogether (plain fp16 operands) is 2-3 orders of magnitude worse: the terms matter
     err_hi_only = float(((ah @ wh.T).double() / (act_scale * ws) - exact).abs().max())
     assert err_hi_only > 50 * err_split
+
+
+# ---- the GELU of the fused kernels (csrc/split_math.h, third form; DESIGN.md 3a') -------------------------------------------
+def _gelu3_constants():
+    """The five coefficients as the kernels carry them (gelu_k3 in split_math.h): parsed from the source, so the test pins
+    what ships."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audioset-convnext-inf_amd", "csrc",
+                            "split_math.h")).read()
+    body = src[src.index("GeluK3 gelu_k3("):]
+    body = body[:body.index("return k;")]
+    c = [float(m) for m in re.findall(r"k\.k[0-4] = (-?[0-9.]+)f \* s;", body)]
+    assert len(c) == 5
+    return c
+
+
+def _f32(x):
+    with np.errstate(over="ignore"):          # a far-out polynomial value overflows to inf, as it does on the GPU
+        return np.asarray(x, np.float64).astype(np.float32).astype(np.float64)
+
+
+def _gelu3_fp32(v, kh=1.0):
+    """gelu3_nano step by step, every instruction's result rounded to fp32 (an FMA = one rounding), in the unit z = 0.5 kh v."""
+    h = 0.5 * kh
+    k = [c / h ** (j + 1) for j, c in enumerate(_gelu3_constants())]       # exact: h is a power of two
+    assert all(abs(x) > 2.0 ** -126 and abs(x) < 2.0 ** 127 for x in k)
+    z = _f32(np.asarray(v, np.float64) * h)
+    a = np.abs(z)
+    q = _f32(a * k[4] + k[3])
+    q = _f32(q * a + k[2]); q = _f32(q * a + k[1]); q = _f32(q * a + k[0])
+    with np.errstate(over="ignore", under="ignore", invalid="raise"):
+        q = _f32(q * a)
+        e = _f32(np.exp2(q))
+    r = _f32(1.0 - e)
+    return _f32(a * r + z) / kh
+
+
+def test_gelu_third_form_error_bound():
+    from scipy.special import erf
+    v = np.linspace(-12.0, 12.0, 480001)
+    ref = 0.5 * v * (1.0 + erf(v / np.sqrt(2.0)))
+    for kh in (1.0, 2.0 ** 11, 2.0 ** -23):                   # the hidden scales acx_finalize can choose (2^-24 .. 2^12)
+        g = _gelu3_fp32(v, kh)
+        err = np.abs(g - ref)
+        assert err.max() <= 1.1e-6, (kh, err.max(), v[err.argmax()])
+        small = np.abs(v) < 0.25                              # E(0) = 1 exactly: relative accuracy near zero
+        assert (err[small] <= 6e-6 * np.abs(ref[small]) + 1e-12).all()
+    # far out: E underflows to 0 (the leading coefficient is positive: no clamp needed), gelu -> v or -0
+    far = np.array([20.0, 1e3, 1e10, 1e30])
+    assert np.array_equal(_gelu3_fp32(far), _f32(far))
+    assert (_gelu3_fp32(-far) == 0.0).all()
