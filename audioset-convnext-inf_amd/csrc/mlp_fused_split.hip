@@ -465,13 +465,7 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
                     unsigned uhi[2], ulo[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        f32x2 v;
-                        v.x = (acc[t][4 * q + 2 * e] - mean) * sc; v.y = (acc[t][4 * q + 2 * e + 1] - mean) * sc;
-                        const h2 h = __builtin_convertvector(v, h2);
-                        const f32x2 back = __builtin_convertvector(h, f32x2);
-                        const h2 l = __builtin_convertvector(v - back, h2);
-                        uhi[e] = __builtin_bit_cast(unsigned, h);
-                        ulo[e] = __builtin_bit_cast(unsigned, l);
+                        acx_split_pair((acc[t][4 * q + 2 * e] - mean) * sc, (acc[t][4 * q + 2 * e + 1] - mean) * sc, uhi[e], ulo[e]);
                         acx_pair_swap(uhi[e], ulo[e]);
                     }
                     // block of channels 32t + 8q .. +7: [8 hi][8 lo]

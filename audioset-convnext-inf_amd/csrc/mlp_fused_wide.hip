@@ -192,13 +192,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             unsigned uh4[4], ul4[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                f32x2 v;
-                v.x = (a[8 * s + 2 * p] - mean) * sc; v.y = (a[8 * s + 2 * p + 1] - mean) * sc;
-                const h2 h = __builtin_convertvector(v, h2);
-                const f32x2 back = __builtin_convertvector(h, f32x2);
-                const h2 l = __builtin_convertvector(v - back, h2);
-                uh4[p] = __builtin_bit_cast(unsigned, h);
-                ul4[p] = __builtin_bit_cast(unsigned, l);
+                acx_split_pair((a[8 * s + 2 * p] - mean) * sc, (a[8 * s + 2 * p + 1] - mean) * sc, uh4[p], ul4[p]);
             }
             acth[pb][s] = __builtin_bit_cast(f32x4, uint4{uh4[0], uh4[1], uh4[2], uh4[3]});
             actl[pb][s] = __builtin_bit_cast(f32x4, uint4{ul4[0], ul4[1], ul4[2], ul4[3]});
@@ -469,13 +463,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             unsigned uhi[2], ulo[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                f32x2 v;
-                v.x = (acc[cb][pb][2 * e] - mean) * sc; v.y = (acc[cb][pb][2 * e + 1] - mean) * sc;
-                const h2 h = __builtin_convertvector(v, h2);
-                const f32x2 back = __builtin_convertvector(h, f32x2);
-                const h2 l = __builtin_convertvector(v - back, h2);
-                uhi[e] = __builtin_bit_cast(unsigned, h);
-                ulo[e] = __builtin_bit_cast(unsigned, l);
+                acx_split_pair((acc[cb][pb][2 * e] - mean) * sc, (acc[cb][pb][2 * e + 1] - mean) * sc, uhi[e], ulo[e]);
                 acx_pair_swap16(uhi[e], ulo[e]);
             }
             if (valid[pb]) *reinterpret_cast<uint4*>(op + cb * 64) = uint4{uhi[0], uhi[1], ulo[0], ulo[1]};

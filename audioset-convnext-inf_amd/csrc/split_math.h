@@ -64,6 +64,14 @@ __device__ __forceinline__ float acx_sub_hi_half(float g, unsigned h, const bool
     return r;
 }
 
+// (x, y) -> packed fp16 hi halves and packed fp16 lo halves (lo = fp16(v - float(hi))): 4 instructions for two values
+__device__ __forceinline__ void acx_split_pair(const float x, const float y, unsigned& hi, unsigned& lo) {
+    f32x2 v; v.x = x; v.y = y;
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
+    f32x2 r; r.x = acx_sub_hi_half(x, hi, false); r.y = acx_sub_hi_half(y, hi, true);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
+}
+
 // ---- GELU + split (third form, round 3; rounds 1-2: A&S 7.1.26 in 17-19 packed, then 15 scalar instructions per element -- git
 // history): 11 vector instructions per element, ONE transcendental --------------------------
 //   erfc(|v| / sqrt 2) ~= E(|v|) = exp2(-|v| Q(|v|)),  Q of degree 4 (five coefficients, leading one positive: -|v| Q -> -inf
