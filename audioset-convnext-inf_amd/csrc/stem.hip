@@ -30,7 +30,7 @@ constexpr int kStemRowF4 = kMels / 4;          // 56 float4 per input row = one 
 
 // OBF: the output tensor is bf16 (ACX_PREC_BF16_ACT): a lane's four channels leave as one 8-byte store
 template <bool OBF>
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, int T, int H0, long long nrows,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void stem_kernel(const float* __restrict__ in, int T, int H0, long long nrows,
                                                    const float* __restrict__ w /*[96][16]*/,
                                                    const float* __restrict__ bias, const float* __restrict__ lnw,
                                                    const float* __restrict__ lnb, void* __restrict__ out_) {
@@ -68,16 +68,25 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
     };
     long long row = blockIdx.x;
     if (row >= nrows) return;
-    float4 nxt = fetch(row);
+    // the rows of the next TWO iterations are in flight while this one is computed: a row is ~1.5 us of arithmetic per workgroup,
+    // an HBM round trip under load is longer (with one row of look-ahead the launch waited for its input: wait_any 0.57).  The
+    // loop is unrolled by two so that each of the two staging registers is written by a load and read two iterations later.
+    const long long g = gridDim.x;
+    float4 pa = fetch(row);
+    float4 pb = row + g < nrows ? fetch(row + g) : make_float4(0.f, 0.f, 0.f, 0.f);
     int buf = 0;
-    for (; row < nrows; row += gridDim.x) {
-        if (stager) patch[buf][sky][sw] = nxt;
-        __syncthreads();                                // this row's patches visible; the other buffer is free again
-        const long long row_n = row + gridDim.x;
-        if (row_n < nrows) nxt = fetch(row_n);          // in flight under this row's arithmetic
+    auto one_row = [&](const long long row, float4& stage) __attribute__((always_inline)) {
+        if (stager) patch[buf][sky][sw] = stage;
+        // a bare barrier behind the LDS writes: __syncthreads() also waits vmcnt(0) -- for the previous row's 347 MB-per-launch
+        // output stores and for the row just requested
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // this row's patches visible; the other buffer is free again
+        if (row + 2 * g < nrows) stage = fetch(row + 2 * g);
         float* orow = reinterpret_cast<float*>(out_) + row * (long long)(kStemW * 96) + ch;
         __bf16* orow_b = reinterpret_cast<__bf16*>(out_) + row * (long long)(kStemW * 96) + ch;
-#pragma unroll
+        // not unrolled, and the kernel held to 128 registers: four waves per SIMD instead of three (unrolled, hipcc hoists the LDS
+        // reads of all seven pixels: 132-146 registers) -- 149 -> 130 us at B = 64
+#pragma unroll 1
         for (int i = 0; i < kStemW / kStemGroups; ++i) {
             const int px = grp + kStemGroups * i;
             float acc[4] = {br[0], br[1], br[2], br[3]};
@@ -105,6 +114,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
             }
         }
         buf ^= 1;
+    };
+    for (; row < nrows; row += 2 * g) {
+        one_row(row, pa);
+        if (row + g < nrows) one_row(row + g, pb);
     }
 }
 
