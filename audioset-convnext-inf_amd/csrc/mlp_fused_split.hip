@@ -7,7 +7,7 @@
 //               normalised activations (x 2^11) as hi/lo halves, resident in C/2 VGPRs: lane (px, h) holds
 //               channels 16s + 8h .. +7 of k-step s
 //     GELU      on the 16 accumulator registers (bias pre-loaded as the initial accumulator), x 2^h, split into
-//               hi/lo halves -- SCALAR fp32 math, 11 VALU per element (split_math.h, gelu3_nano).  The file is built
+//               hi/lo halves -- SCALAR fp32 math, 10.5 VALU per element (split_math.h, gelu3_nano).  The file is built
 //               with -fno-slp-vectorize: beside MFMAs a packed-FP32 instruction costs far more than the two scalar
 //               ones it replaces (round 2 ran this kernel on v_pk_fma_f32 / v_pk_mul_f32: 104 of them per 36 MFMAs,
 //               0.25 of the matrix peak; profiles/r03_a_coissue_table.txt prices one v_pk_fma_f32 in an MFMA gap at +18 cycles)
@@ -215,10 +215,10 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
             const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 32 * (j_) + 8 * q + 4 * hh);                 \
             Xacc_[4 * q + 0] = bq[0]; Xacc_[4 * q + 1] = bq[1]; Xacc_[4 * q + 2] = bq[2]; Xacc_[4 * q + 3] = bq[3]; \
         }
-    // GELU steps [from, to) of the kGeluSteps = 8 x 22 single instructions that turn X_ into the packed halves gh_ / gl_ (8 words
+    // GELU steps [from, to) of the kGeluSteps = 8 x 21 single instructions that turn X_ into the packed halves gh_ / gl_ (8 words
     // each: the B operand of the next iteration's phase 2, k-step s' = words 4 s' .. 4 s' + 3): step m works on register pair
-    // 2 (m / 44) + (m & 1) -- two pairs alternate, so neighbouring steps do not depend on each other -- and is step (m % 44) / 2
-    // of that pair's twenty-two (split_math.h, gelu3_nano)
+    // 2 (m / 42) + (m & 1) -- two pairs alternate, so neighbouring steps do not depend on each other -- and is step (m % 42) / 2
+    // of that pair's twenty-one (split_math.h, gelu3_nano)
 #define ACX_NANO_CASE(I_, X_, gh_, gl_) else if (st_ == (I_)) gelu3_nano<(I_)>(gs_, gk, X_[2 * pr_], X_[2 * pr_ + 1], gh_[pr_], gl_[pr_]);
 #define ACX_MICRO(X_, gh_, gl_, from_, to_)                                                                     \
         _Pragma("unroll") for (int mm_ = (from_); mm_ < (to_); ++mm_) {                                         \
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
             if (st_ == 0) gelu3_nano<0>(gs_, gk, X_[2 * pr_], X_[2 * pr_ + 1], gh_[pr_], gl_[pr_]);             \
             ACX_NANO_CASE(1, X_, gh_, gl_) ACX_NANO_CASE(2, X_, gh_, gl_) ACX_NANO_CASE(3, X_, gh_, gl_) ACX_NANO_CASE(4, X_, gh_, gl_) ACX_NANO_CASE(5, X_, gh_, gl_) ACX_NANO_CASE(6, X_, gh_, gl_) ACX_NANO_CASE(7, X_, gh_, gl_) \
             ACX_NANO_CASE(8, X_, gh_, gl_) ACX_NANO_CASE(9, X_, gh_, gl_) ACX_NANO_CASE(10, X_, gh_, gl_) ACX_NANO_CASE(11, X_, gh_, gl_) ACX_NANO_CASE(12, X_, gh_, gl_) ACX_NANO_CASE(13, X_, gh_, gl_) ACX_NANO_CASE(14, X_, gh_, gl_) \
-            ACX_NANO_CASE(15, X_, gh_, gl_) ACX_NANO_CASE(16, X_, gh_, gl_) ACX_NANO_CASE(17, X_, gh_, gl_) ACX_NANO_CASE(18, X_, gh_, gl_) ACX_NANO_CASE(19, X_, gh_, gl_) ACX_NANO_CASE(20, X_, gh_, gl_) ACX_NANO_CASE(21, X_, gh_, gl_) \
+            ACX_NANO_CASE(15, X_, gh_, gl_) ACX_NANO_CASE(16, X_, gh_, gl_) ACX_NANO_CASE(17, X_, gh_, gl_) ACX_NANO_CASE(18, X_, gh_, gl_) ACX_NANO_CASE(19, X_, gh_, gl_) ACX_NANO_CASE(20, X_, gh_, gl_) \
         }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first tile: W1c(0..2), W2c(0), y landed ...
@@ -281,12 +281,7 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
                 unsigned u4h[4], u4l[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    f32x2 v;
-                    v.x = (a[8 * s + 2 * p] - mean) * sc; v.y = (a[8 * s + 2 * p + 1] - mean) * sc;
-                    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
-                    f32x2 r; r.x = acx_sub_hi_half(v.x, h, false); r.y = acx_sub_hi_half(v.y, h, true);
-                    u4h[p] = h;
-                    u4l[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
+                    acx_split_pair((a[8 * s + 2 * p] - mean) * sc, (a[8 * s + 2 * p + 1] - mean) * sc, u4h[p], u4l[p]);
                 }
                 acth[s] = __builtin_bit_cast(f32x4, uint4{u4h[0], u4h[1], u4h[2], u4h[3]});
                 actl[s] = __builtin_bit_cast(f32x4, uint4{u4l[0], u4l[1], u4l[2], u4l[3]});

@@ -22,7 +22,7 @@
 //               LDS holds a ring of three segments: one being multiplied, one landed or landing, one being requested.
 //   schedule    segment 2k-1: phase 1 of chunk k    X^T[32 hidden x 32 px] = W1c . LN(y)^T     3 C/16 MFMA pairs (one per pixel block)
 //               segment 2k  : phase 2 of chunk k-1  out^T[C x 32 px] += W2c . G(k-1)            3 C/16 MFMA pairs
-//               GELU + hi/lo split of X(k) -> G(k): 22 single-instruction "nano-steps" per register pair (split_math.h,
+//               GELU + hi/lo split of X(k) -> G(k): 21 single-instruction "nano-steps" per register pair (split_math.h,
 //               gelu3_nano), half of the pairs dealt over the MFMAs of segment 2k, the other half over those of segment
 //               2k+1.  One wave per SIMD issues both streams: about five single-issue instructions ride for free behind
 //               32 cycles of matrix work (a 32x32x16 MFMA then, a pair of 16x16x32 now), every further one costs ~5 cycles
@@ -98,7 +98,7 @@ struct WideCfg {
         return cum_cap_units(u) + (pos == 0 ? c0 : pos == 1 ? c0 + 1 : pos == 2 ? c0 + 3 : pos == 3 ? c0 + 5 : pos == 4 ? c0 + 6 : c0 + 7);
     }
     // what does not fit the gaps is issued at the top of the segment, right behind the reads of its first three fragment pairs
-    // (nothing since the GELU is 22 steps per pair: 88 per segment against 102 slots at C = 192; it was 120 with the 30-step form)
+    // (nothing since the GELU is 21 steps per pair: 84 per segment against 102 slots at C = 192; it was 120 with the 30-step form)
     static constexpr int kCapTotal = cum_cap_units(kUnits);
     static constexpr int kNanoHead = kNano > kCapTotal ? ((kNano - kCapTotal + 1) / 2) * 2 : 0;
     __host__ __device__ static constexpr int nano_end(int m) {      // nano-steps issued once the gap behind MFMA m is done
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #define ACX_M16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ACX_H8(a_), ACX_H8(b_), c_, 0, 0, 0);
     // phase-2 unit i_ = block cb of 16 out channels; K = the chunk's 32 hidden units in ONE step
 #define ACX_W2_RD(base_, i_, pl_) (*reinterpret_cast<const f32x4*>((base_) + (i_) * (16 * 128) + w2off[pl_]))
-    // nano-steps [from, to) of the kNano that segment half half_ carries: step ng_ is instruction (ng_ % 44) / 2 of register pair
-    // 4 half_ + 2 (ng_ / 44) + (ng_ & 1) (split_math.h, gelu3_nano): pair after pair, in order.  Pair pr = 4 pb + 2 hb + e covers registers
+    // nano-steps [from, to) of the kNano that segment half half_ carries: step ng_ is instruction (ng_ % 42) / 2 of register pair
+    // 4 half_ + 2 (ng_ / 42) + (ng_ & 1) (split_math.h, gelu3_nano): pair after pair, in order.  Pair pr = 4 pb + 2 hb + e covers registers
     // 2 e, 2 e + 1 of X block 2 pb + hb: hidden units 16 hb + 4 g4 + 2 e, + 1 of pixel block pb
 #define ACX_NANO_ARGS gsv[w_], gk, Xv[(2 * pr_) >> 2][(2 * pr_) & 3], Xv[(2 * pr_) >> 2][((2 * pr_) & 3) + 1], uh[0][pr_], ul[0][pr_]
 #define ACX_NANO_CASE(I_) else if (st_ == (I_)) gelu3_nano<(I_)>(ACX_NANO_ARGS);
@@ -263,7 +263,6 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             ACX_NANO_CASE(18)                                                                                    \
             ACX_NANO_CASE(19)                                                                                    \
             ACX_NANO_CASE(20)                                                                                    \
-            ACX_NANO_CASE(21)                                                                                    \
         }
 #define ACX_TOUCH2(h_, l_) asm volatile("" :: "v"(h_), "v"(l_));
 #define ACX_BIAS_INIT(j_)                                                                                       \

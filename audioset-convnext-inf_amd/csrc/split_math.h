@@ -56,24 +56,25 @@ __device__ __forceinline__ unsigned acx_lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(p);
 }
 
-// g - float(one fp16 half of h) in ONE instruction (v_fma_mix_f32 reads the half straight from the packed register)
-__device__ __forceinline__ float acx_sub_hi_half(float g, unsigned h, const bool upper) {
-    float r;
-    if (upper) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(g), "v"(h));
-    else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(g), "v"(h));
-    return r;
+// fp16(g - float(half of h)) written straight into one half of a packed register: v_fma_mixlo_f16 / v_fma_mixhi_f16 (the fma is
+// evaluated in fp32 -- exactly, the operands are within a factor 2^11 -- and rounded once, as v_fma_mix_f32 + v_cvt_pk_f16_f32
+// did with one instruction more per pair; bit-identical on 2^20 random pairs including the subnormal range)
+__device__ __forceinline__ void acx_lo_half_lower(unsigned& lo, float gx, unsigned h) {
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(gx), "v"(h));
 }
-
-// (x, y) -> packed fp16 hi halves and packed fp16 lo halves (lo = fp16(v - float(hi))): 4 instructions for two values
+__device__ __forceinline__ void acx_lo_half_upper(unsigned& lo, float gy, unsigned h) {
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(gy), "v"(h));
+}
+// (x, y) -> packed fp16 hi halves and packed fp16 lo halves (lo = fp16(v - float(hi))): 3 instructions for two values
 __device__ __forceinline__ void acx_split_pair(const float x, const float y, unsigned& hi, unsigned& lo) {
     f32x2 v; v.x = x; v.y = y;
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
-    f32x2 r; r.x = acx_sub_hi_half(x, hi, false); r.y = acx_sub_hi_half(y, hi, true);
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
+    acx_lo_half_lower(lo, x, hi);
+    acx_lo_half_upper(lo, y, hi);
 }
 
 // ---- GELU + split (third form, round 3; rounds 1-2: A&S 7.1.26 in 17-19 packed, then 15 scalar instructions per element -- git
-// history): 11 vector instructions per element, ONE transcendental --------------------------
+// history): 10.5 vector instructions per element, ONE transcendental --------------------------
 //   erfc(|v| / sqrt 2) ~= E(|v|) = exp2(-|v| Q(|v|)),  Q of degree 4 (five coefficients, leading one positive: -|v| Q -> -inf
 //   for large |v|, E -> 0 without a clamp; E(0) = 1 exactly, so the relative accuracy near 0 is kept)
 //   gelu(v) = 0.5 v + 0.5 |v| (1 - E):  minimax fit of 0.5 |v| (E - erfc) over [0, 9] (tools/lab/fit_gelu.py):
@@ -84,9 +85,9 @@ __device__ __forceinline__ void acx_split_pair(const float x, const float y, uns
 //   g = gelu(v) kH = z + |z| (1 - E),   exp2 argument = |z| (K0 + K1 |z| + ... + K4 |z|^4),  Kj = -cj / (0.5 kH)^(j+1)
 // (exact scalings of the five constants; 0.5 kH = 2^-25 .. 2^11 keeps every Kj a normal number, api.hip hidden_scale_for).
 // For v << 0 the two terms cancel with an absolute error of |v| kH 2^-25 -- what the reference's own fp32 evaluation of
-// 0.5 v (1 + erf) carries there.  The fp32 -> fp16 hi / lo split is v_cvt_pk_f16_f32 + v_fma_mix_f32 (g - float(hi) in one
-// instruction per element, straight from the packed hi halves) + v_cvt_pk_f16_f32.  TWENTY-TWO single-instruction steps per
-// register pair (two values), four registers of state.
+// 0.5 v (1 + erf) carries there.  The fp32 -> fp16 hi / lo split is v_cvt_pk_f16_f32 for the hi halves and one v_fma_mixlo_f16 /
+// v_fma_mixhi_f16 per element for fp16(g - float(hi)).  TWENTY-ONE single-instruction steps per register pair (two values),
+// four registers of state.
 struct GeluK3 { float zs, k0, k1, k2, k3, k4; };
 __device__ __forceinline__ GeluK3 gelu_k3(float sinv, float kh) {
     GeluK3 k;
@@ -107,7 +108,7 @@ __device__ __forceinline__ void gelu_k3_to_vgprs(GeluK3& k) {
     asm volatile("" : "+v"(k.zs), "+v"(k.k0), "+v"(k.k1), "+v"(k.k2), "+v"(k.k3), "+v"(k.k4));
 }
 struct GeluState3 { float zx, zy, qx, qy; };
-constexpr int kGelu3Nano = 22;      // steps per register pair
+constexpr int kGelu3Nano = 21;      // steps per register pair
 // step I of the pair (ax, ay) -> packed halves (hi, lo); ax / ay are read by steps 0 and 1 only
 template <int I>
 __device__ __forceinline__ void gelu3_nano(GeluState3& s, const GeluK3 k, const float ax, const float ay, unsigned& hi, unsigned& lo) {
@@ -130,9 +131,8 @@ __device__ __forceinline__ void gelu3_nano(GeluState3& s, const GeluK3 k, const 
     else if constexpr (I == 16) s.qx = __builtin_fmaf(__builtin_fabsf(s.zx), s.qx, s.zx);     // g
     else if constexpr (I == 17) s.qy = __builtin_fmaf(__builtin_fabsf(s.zy), s.qy, s.zy);
     else if constexpr (I == 18) { f32x2 g; g.x = s.qx; g.y = s.qy; hi = __builtin_bit_cast(unsigned, __builtin_convertvector(g, h2)); }
-    else if constexpr (I == 19) s.zx = acx_sub_hi_half(s.qx, hi, false);
-    else if constexpr (I == 20) s.zy = acx_sub_hi_half(s.qy, hi, true);
-    else { f32x2 r; r.x = s.zx; r.y = s.zy; lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2)); }
+    else if constexpr (I == 19) acx_lo_half_lower(lo, s.qx, hi);
+    else acx_lo_half_upper(lo, s.qy, hi);
 }
 // the whole pair at once (epilogues: nothing to interleave with)
 __device__ __forceinline__ void gelu3_pair(const GeluK3 k, const float ax, const float ay, unsigned& hi, unsigned& lo) {
@@ -144,7 +144,6 @@ __device__ __forceinline__ void gelu3_pair(const GeluK3 k, const float ax, const
     gelu3_nano<12>(s, k, ax, ay, hi, lo); gelu3_nano<13>(s, k, ax, ay, hi, lo); gelu3_nano<14>(s, k, ax, ay, hi, lo);
     gelu3_nano<15>(s, k, ax, ay, hi, lo); gelu3_nano<16>(s, k, ax, ay, hi, lo); gelu3_nano<17>(s, k, ax, ay, hi, lo);
     gelu3_nano<18>(s, k, ax, ay, hi, lo); gelu3_nano<19>(s, k, ax, ay, hi, lo); gelu3_nano<20>(s, k, ax, ay, hi, lo);
-    gelu3_nano<21>(s, k, ax, ay, hi, lo);
 }
 
 // The third form in SEVEN micro-steps of 2-4 instructions for a register pair, result left in (s.qx, s.qy) -- the bf16 kernels
