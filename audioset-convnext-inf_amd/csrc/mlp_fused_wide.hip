@@ -402,12 +402,17 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     grp = grp == 2 ? 0 : grp + 1;
     // the activations are dead from here on: their registers take the residual x of the tile, requested two segments
     // (~2 us) before the epilogue needs it
-    f32x4 xr[2][C / 16];
+    // (C = 384: all but the last kLateX blocks per pixel block -- with all 48 in flight hipcc spilled three of them, each spill a
+    // load + s_waitcnt vmcnt(0) + scratch store, i.e. three serial HBM round trips in the middle of the tile; the late ones are
+    // requested at the top of the epilogue, into registers the loop has freed by then)
+    constexpr int kLateX = C >= 384 ? 2 : 0;
+    constexpr int kEarlyX = C / 16 - kLateX;
+    f32x4 xr[2][kEarlyX];
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
         const float* xp = x + mrow[pb] * C + 4 * g4;
 #pragma unroll
-        for (int cb = 0; cb < C / 16; ++cb) xr[pb][cb] = *reinterpret_cast<const f32x4*>(xp + 16 * cb);
+        for (int cb = 0; cb < kEarlyX; ++cb) xr[pb][cb] = *reinterpret_cast<const f32x4*>(xp + 16 * cb);
     }
     phase2(std::true_type{}, 2 * n - 2, grp);
     grp = grp == 2 ? 0 : grp + 1;
@@ -429,6 +434,12 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #undef ACX_SEG_END
 
     // ---- epilogue: lane (px = l15 of block pb, g4), block cb: channels 16 cb + 4 g4 .. + 3  ->  x = x + out + b2 ---------
+    f32x4 xl[2][kLateX > 0 ? kLateX : 1];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int i = 0; i < kLateX; ++i) xl[pb][i] = *reinterpret_cast<const f32x4*>(x + mrow[pb] * C + 4 * g4 + 16 * (kEarlyX + i));
+#define ACX_XR(pb_, cb_) ((cb_) < kEarlyX ? xr[pb_][(cb_) < kEarlyX ? (cb_) : 0] : xl[pb_][(cb_) >= kEarlyX ? (cb_) - kEarlyX : 0])
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
     if constexpr (LNOUT) {
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #pragma unroll
         for (int cb = 0; cb < C / 16; ++cb) {
             const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * cb + 4 * g4);
-            const f32x4 v = xr[pb][cb];
+            const f32x4 v = ACX_XR(pb, cb);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[cb][pb][e] = v[e] + fmaf(acc[cb][pb][e], sinv2, bb[e]);
             sum += (acc[cb][pb][0] + acc[cb][pb][1]) + (acc[cb][pb][2] + acc[cb][pb][3]);
@@ -472,13 +483,14 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #pragma unroll
         for (int cb = 0; cb < C / 16; ++cb) {
             const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * cb + 4 * g4);
-            f32x4 v = xr[pb][cb];
+            f32x4 v = ACX_XR(pb, cb);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += fmaf(acc[cb][pb][e], sinv2, bb[e]);
             *reinterpret_cast<f32x4*>(xp + 16 * cb) = v;
         }
     }
     }
+#undef ACX_XR
     ACX_WSTAMP(4)
     ACX_WSTAMP_FLUSH
 }
