@@ -156,9 +156,15 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(0, p, 0)
 #pragma unroll
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(1, p, 1)
-    {
-        const float b1scale = 1.0f / sinv1;             // a power of two
-        for (int i = tid; i < 4 * C; i += Cfg::kThreads) b1s[i] = b1[i] * b1scale;
+    // bias staging: 16 bytes per lane, requested here (ahead of the tile's rows: vmcnt completes in order) and written to the LDS
+    // after the rows have been normalised -- no wait of its own (a rolled scalar loop in this place was 4C / 256 dependent round
+    // trips in front of the row loads)
+    constexpr int kB1Iters = (C + Cfg::kThreads - 1) / Cfg::kThreads;
+    float4 b1v[kB1Iters];
+#pragma unroll
+    for (int q = 0; q < kB1Iters; ++q) {
+        const int i = q * Cfg::kThreads + tid;
+        b1v[q] = reinterpret_cast<const float4*>(b1)[i < C ? i : 0];
     }
 
     // ---- this wave's activations: lane (px = l15 of block pb, k block g4) holds channels 32 s + 8 g4 .. + 7, s = 0..C/32-1 ----
@@ -199,6 +205,16 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         }
     }
 
+    {
+        const float b1scale = 1.0f / sinv1;             // a power of two
+#pragma unroll
+        for (int q = 0; q < kB1Iters; ++q) {
+            const int i = q * Cfg::kThreads + tid;
+            float4 v = b1v[q];
+            v.x *= b1scale; v.y *= b1scale; v.z *= b1scale; v.w *= b1scale;
+            if (i < C) reinterpret_cast<float4*>(b1s)[i] = v;
+        }
+    }
     f32x4 acc[C / 16][2];         // out^T: block cb = 16 out channels x pixel block pb; lane holds channels 16 cb + 4 g4 .. + 3
 #pragma unroll
     for (int cb = 0; cb < C / 16; ++cb)

@@ -111,7 +111,12 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(0, p, 0)
 #pragma unroll
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(1, p, 1)
-    for (int i = tid; i < 4 * C; i += Cfg::kThreads) b1s[i] = b1[i];
+    // 16 bytes per lane, every load of the staging issued before the first wait (a rolled scalar loop was 4C / 256 dependent round trips)
+#pragma unroll
+    for (int i0 = 0; i0 < C; i0 += Cfg::kThreads) {
+        const int i = i0 + tid;
+        if (i < C) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(b1)[i];
+    }
 
     // ---- this wave's activations: lane (px = l31, half hh) holds channels 16s + 8hh .. +7 as 8 bf16, s = 0..C/16-1 ----
     f32x4 act[PT][Cfg::kSteps];
