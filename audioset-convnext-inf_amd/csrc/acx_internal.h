@@ -182,6 +182,7 @@ struct acx_ctx {
     // an HBM-bound kernel of one half fills the matrix-pipe-bound phases of the other and vice versa
     bool split_streams = true;    // ACX_SPLIT_STREAMS=0 turns it off
     int split_ways = 0;           // ACX_SPLIT_WAYS=n forces n sub-batches (1 .. kMaxSplitWays); 0: the per-arithmetic default
+    int inflight_ways = 1;       // sub-batches of the forward being queued (acx_forward): tile-shape choices of small launches see the others
     // fork/join resources per CALLER stream: forwards issued on different streams (or threads) never share an event.
     // Sub-batch 0 runs on the caller's stream, sub-batch i > 0 on streams[i - 1].
     static constexpr int kMaxSplitWays = 4;
@@ -273,5 +274,21 @@ int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const void* y
 int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
                      hipStream_t s);
 int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, int W, int C, hipStream_t s);
+
+// number of CUs of the current device (one persistent workgroup each), cached per device
+inline int cu_count_of_current_device(int* out) {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    ACX_HIP(hipGetDevice(&dev));
+    int v = cache[dev & 63].load(std::memory_order_acquire);
+    if (v == 0) {
+        ACX_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        if (v <= 0) ACX_FAIL(ACX_ERR_HIP, "device %d reports %d compute units", dev, v);
+        cache[dev & 63].store(v, std::memory_order_release);
+    }
+    *out = v;
+    return ACX_OK;
+}
+
 
 }  // namespace acx

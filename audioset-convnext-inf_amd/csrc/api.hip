@@ -843,8 +843,11 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
                                                            : (mode == ACX_MODE_SCENE ? (size_t)kDims[3] : (size_t)kClasses);
             hipStream_t si = i == 0 ? st : aux.streams[i - 1];
             if (i > 0) ACX_HIP(hipStreamWaitEvent(si, aux.fork, 0));
-            ACX_TRY(forward_one(c, wav + (size_t)b_off * L, Bi, L, mode, out0 + b_off * per_clip,
-                                out1 ? out1 + b_off * per_clip : nullptr, ws + ws_off, pi, si));
+            c->inflight_ways = ways;
+            const int rc = forward_one(c, wav + (size_t)b_off * L, Bi, L, mode, out0 + b_off * per_clip,
+                                       out1 ? out1 + b_off * per_clip : nullptr, ws + ws_off, pi, si);
+            c->inflight_ways = 1;
+            if (rc != ACX_OK) return rc;
             if (i > 0) {
                 ACX_HIP(hipEventRecord(aux.joins[i - 1], si));
                 ACX_HIP(hipStreamWaitEvent(st, aux.joins[i - 1], 0));

@@ -508,21 +508,6 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
 #undef ACX_MICRO
 }
 
-// number of CUs of the current device (one persistent workgroup each), cached per device
-static int cu_count_of_current_device(int* out) {
-    static std::atomic<int> cache[64];
-    int dev = 0;
-    ACX_HIP(hipGetDevice(&dev));
-    int v = cache[dev & 63].load(std::memory_order_acquire);
-    if (v == 0) {
-        ACX_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        if (v <= 0) ACX_FAIL(ACX_ERR_HIP, "device %d reports %d compute units", dev, v);
-        cache[dev & 63].store(v, std::memory_order_release);
-    }
-    *out = v;
-    return ACX_OK;
-}
-
 template <int C, bool LNOUT>
 static int launch_fused_s_cfg(const BlockW& w, const float* y, float* x, long long M, void* ln_out, hipStream_t s) {
     using Cfg = FusedSCfg<C>;

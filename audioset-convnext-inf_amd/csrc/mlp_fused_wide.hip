@@ -33,6 +33,7 @@
 // HBM traffic per block: read y, read x, write x (3 C H W 4 bytes) + the weight stream from L2 / MALL.
 #include <type_traits>
 
+#include <cstdlib>
 #include "acx_internal.h"
 #include "split_math.h"
 
@@ -111,7 +112,9 @@ struct WideCfg {
 
 // byte offset of segment s in the stream: order W1(0) W1(1) W2(0) W1(2) W2(1) ... (see the header)
 //   W1(k): k == 0 ? 0 : 2k - 1       W2(k): k == n - 1 ? 2n - 1 : 2k + 2
-template <int C, int PT, bool LNOUT>
+// NPB = 16-pixel blocks per wave: 2 (a 128-pixel tile per workgroup), or 1 for launches whose 64-pixel tiles all find a CU at
+// once (small batches: twice the workgroups, ~0.65 of the time each; the arithmetic of a pixel is the same in both)
+template <int C, int PT, bool LNOUT, int NPB>
 __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     const float* __restrict__ y, float* __restrict__ x, const char* __restrict__ wstream /*[2n][128 C bytes]*/,
     const float* __restrict__ b1, const float* __restrict__ b2, long long M, float sinv1, float sinv2, float hscale,
@@ -133,9 +136,9 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     bool valid[2];
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
-        mrow[pb] = (long long)blockIdx.x * Cfg::kPix + wave * 32 + pb * 16 + l15;
-        valid[pb] = mrow[pb] < M;
-        if (!valid[pb]) mrow[pb] = M - 1;
+        mrow[pb] = (long long)blockIdx.x * (Cfg::kWaves * 16 * NPB) + wave * (16 * NPB) + (pb < NPB ? pb : 0) * 16 + l15;
+        valid[pb] = pb < NPB && mrow[pb] < M;
+        if (mrow[pb] >= M) mrow[pb] = M - 1;
     }
 
     constexpr int n = Cfg::kChunks;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     constexpr int kS32 = C / 32;
     f32x4 acth[2][kS32], actl[2][kS32];                         // 8 fp16 halves each
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
+    for (int pb = 0; pb < NPB; ++pb) {
         float a[C / 4];
         const float* yp = y + mrow[pb] * C + 8 * g4;
 #pragma unroll
@@ -310,7 +313,9 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 
     // one phase-1 segment: X = b1 + W1c . LN(y)^T for chunk k_, image in ring slot grp_, requesting segment seg_ + 2
     auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
-        constexpr bool HV = decltype(with_gelu)::value;     // second half of the GELU of Xv rides on this segment's MFMAs
+        // second half of the GELU of Xv (the pairs of pixel block 1) rides on this segment's MFMAs
+        constexpr bool HV = decltype(with_gelu)::value && NPB == 2;
+        constexpr bool kPack = decltype(with_gelu)::value;
         const char* base = smem + grp_ * Cfg::kSegBytes;
         const bool dma = seg_ + 2 < Cfg::kSegs;
         const int g2 = (grp_ + 2) % 3;
@@ -331,17 +336,17 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             ACX_M16(cl_, acth[0][(u_) >> 1], Xn[(u_) & 1])                                                      \
             if ((u_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (u_) / Cfg::kDmaStride, g2) }          \
             ACX_NANO_AT(HV, 1, 6 * (u_) + 0)                                                                    \
-            ACX_M16(cl_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                \
+            if constexpr (NPB == 2) { ACX_M16(cl_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)]) }                        \
             if ((u_) + 3 < Cfg::kSteps) cl_ = ACX_W1_RD(base, (u_) + 3, 1);                                     \
             ACX_NANO_AT(HV, 1, 6 * (u_) + 1)                                                                    \
             ACX_M16(ch_, actl[0][(u_) >> 1], Xn[(u_) & 1])                                                      \
             ACX_NANO_AT(HV, 1, 6 * (u_) + 2)                                                                    \
-            ACX_M16(ch_, actl[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                \
+            if constexpr (NPB == 2) { ACX_M16(ch_, actl[1][(u_) >> 1], Xn[2 + ((u_) & 1)]) }                        \
             ACX_NANO_AT(HV, 1, 6 * (u_) + 3)                                                                    \
             ACX_M16(ch_, acth[0][(u_) >> 1], Xn[(u_) & 1])                                                      \
             if ((u_) + 1 < Cfg::kSteps) ACX_TOUCH2(th_, tl_)                                                    \
             ACX_NANO_AT(HV, 1, 6 * (u_) + 4)                                                                    \
-            ACX_M16(ch_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)])                                                \
+            if constexpr (NPB == 2) { ACX_M16(ch_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)]) }                        \
             if ((u_) + 3 < Cfg::kSteps) ch_ = ACX_W1_RD(base, (u_) + 3, 0);                                     \
             ACX_NANO_AT(HV, 1, 6 * (u_) + 5)                                                                    \
             ACX_FENCE
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             ACX_P1_UNIT(s + 2, f2h, f2l, f0h, f0l)
         }
 #undef ACX_P1_UNIT
-        if constexpr (HV) { ACX_PACK_G() }
+        if constexpr (kPack) { ACX_PACK_G() }
 #pragma unroll
         for (int q = 0; q < 4; ++q) Xv[q] = Xn[q];
         ACX_SEG_END(dma, 1)
@@ -375,17 +380,17 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             ACX_M16(cl_, gh[0], acc[i_][0])                                                                     \
             if ((i_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (i_) / Cfg::kDmaStride, g2) }          \
             ACX_NANO_AT(HV, 0, 6 * (i_) + 0)                                                                    \
-            ACX_M16(cl_, gh[1], acc[i_][1])                                                                     \
+            if constexpr (NPB == 2) { ACX_M16(cl_, gh[1], acc[i_][1]) }                                         \
             if ((i_) + 3 < Cfg::kUnits) cl_ = ACX_W2_RD(base, (i_) + 3, 1);                                     \
             ACX_NANO_AT(HV, 0, 6 * (i_) + 1)                                                                    \
             ACX_M16(ch_, gl[0], acc[i_][0])                                                                     \
             ACX_NANO_AT(HV, 0, 6 * (i_) + 2)                                                                    \
-            ACX_M16(ch_, gl[1], acc[i_][1])                                                                     \
+            if constexpr (NPB == 2) { ACX_M16(ch_, gl[1], acc[i_][1]) }                                         \
             ACX_NANO_AT(HV, 0, 6 * (i_) + 3)                                                                    \
             ACX_M16(ch_, gh[0], acc[i_][0])                                                                     \
             if ((i_) + 1 < Cfg::kUnits) ACX_TOUCH2(th_, tl_)                                                    \
             ACX_NANO_AT(HV, 0, 6 * (i_) + 4)                                                                    \
-            ACX_M16(ch_, gh[1], acc[i_][1])                                                                     \
+            if constexpr (NPB == 2) { ACX_M16(ch_, gh[1], acc[i_][1]) }                                         \
             if ((i_) + 3 < Cfg::kUnits) ch_ = ACX_W2_RD(base, (i_) + 3, 0);                                     \
             ACX_NANO_AT(HV, 0, 6 * (i_) + 5)                                                                    \
             ACX_FENCE
@@ -425,14 +430,14 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     constexpr int kEarlyX = C / 16 - kLateX;
     f32x4 xr[2][kEarlyX];
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
+    for (int pb = 0; pb < NPB; ++pb) {
         const float* xp = x + mrow[pb] * C + 4 * g4;
 #pragma unroll
         for (int cb = 0; cb < kEarlyX; ++cb) xr[pb][cb] = *reinterpret_cast<const f32x4*>(xp + 16 * cb);
     }
     phase2(std::true_type{}, 2 * n - 2, grp);
     grp = grp == 2 ? 0 : grp + 1;
-    ACX_NANO_RANGE(1, 0, Cfg::kNano)       // second half of the last chunk's GELU: no phase-1 segment left to ride on
+    if constexpr (NPB == 2) { ACX_NANO_RANGE(1, 0, Cfg::kNano) }      // second half of the last chunk's GELU: no phase-1 segment left to ride on
     ACX_PACK_G()
     phase2(std::false_type{}, 2 * n - 1, grp);
 #undef ACX_WDMA
@@ -452,12 +457,12 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     // ---- epilogue: lane (px = l15 of block pb, g4), block cb: channels 16 cb + 4 g4 .. + 3  ->  x = x + out + b2 ---------
     f32x4 xl[2][kLateX > 0 ? kLateX : 1];
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
+    for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
         for (int i = 0; i < kLateX; ++i) xl[pb][i] = *reinterpret_cast<const f32x4*>(x + mrow[pb] * C + 4 * g4 + 16 * (kEarlyX + i));
 #define ACX_XR(pb_, cb_) ((cb_) < kEarlyX ? xr[pb_][(cb_) < kEarlyX ? (cb_) : 0] : xl[pb_][(cb_) >= kEarlyX ? (cb_) - kEarlyX : 0])
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
+    for (int pb = 0; pb < NPB; ++pb) {
     if constexpr (LNOUT) {
         // last block of the stage in the full forward: the only reader of the new x is the LayerNorm in front of the
         // downsample conv (convnext.py:230-235): write its S16 operand instead (see mlp_fused_split.hip)
@@ -511,14 +516,15 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     ACX_WSTAMP_FLUSH
 }
 
-template <int C, int PT, bool LNOUT>
+template <int C, int PT, bool LNOUT, int NPB>
 static int launch_wide_cfg(const BlockW& w, const float* y, float* x, long long M, void* ln_out, hipStream_t s) {
     using Cfg = WideCfg<C, PT>;
     static_assert(Cfg::kLdsBytes <= kCuLdsBytes, "weight ring does not fit the LDS");
     static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_kernel<C, PT, LNOUT>, kCuLdsBytes));
-    const long long blocks = (M + Cfg::kPix - 1) / Cfg::kPix;
-    mlp_fused_wide_kernel<C, PT, LNOUT><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s>>>(
+    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_kernel<C, PT, LNOUT, NPB>, kCuLdsBytes));
+    constexpr int kPixT = Cfg::kWaves * 16 * NPB;
+    const long long blocks = (M + kPixT - 1) / kPixT;
+    mlp_fused_wide_kernel<C, PT, LNOUT, NPB><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s>>>(
         y, x, reinterpret_cast<const char*>(w.wstream_s), w.b1, w.b2, M, 1.0f / (kSplitLnScale * w.w1s_scale),
         1.0f / (w.hid_scale * w.w2s_scale), w.hid_scale, reinterpret_cast<char*>(ln_out));
     ACX_HIP(hipGetLastError());
@@ -531,8 +537,18 @@ int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, fl
                           void* ln_out) {
     if (!w.wstream_s) ACX_FAIL(ACX_ERR_STATE, "wide fused MLP: the weight stream was not packed for C=%d", C);
     ProfScope ps(c, ACX_K_MLP_WIDE, s);
-    if (C == 384) return ln_out ? launch_wide_cfg<384, 1, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<384, 1, false>(w, y, x, M, nullptr, s);
-    if (C == 192) return ln_out ? launch_wide_cfg<192, 1, true>(w, y, x, M, ln_out, s) : launch_wide_cfg<192, 1, false>(w, y, x, M, nullptr, s);
+    // 64-pixel tiles (one 16-pixel block per wave) when all of them -- of every sub-batch in flight -- find a CU at once: a small
+    // batch then spreads over twice the CUs at ~0.65 of the time per tile; beyond that the 128-pixel tile is the efficient one.
+    // The arithmetic of a pixel does not depend on the choice (same MFMA order, same GELU): results are bit-identical.
+    int cus = 0;
+    ACX_TRY(cu_count_of_current_device(&cus));
+    const int ways = c && c->inflight_ways > 0 ? c->inflight_ways : 1;
+    bool half = (M + 63) / 64 * ways <= cus;
+    if (const char* e = std::getenv("ACX_WIDE_NPB")) half = e[0] == '1' ? true : (e[0] == '2' ? false : half);
+#define ACX_GO(C_, LN_) (half ? launch_wide_cfg<C_, 1, LN_, 1>(w, y, x, M, LN_ ? ln_out : nullptr, s) : launch_wide_cfg<C_, 1, LN_, 2>(w, y, x, M, LN_ ? ln_out : nullptr, s))
+    if (C == 384) return ln_out ? ACX_GO(384, true) : ACX_GO(384, false);
+    if (C == 192) return ln_out ? ACX_GO(192, true) : ACX_GO(192, false);
+#undef ACX_GO
     ACX_FAIL(ACX_ERR_SHAPE, "wide fused MLP: unsupported channel count %d", C);
 }
 

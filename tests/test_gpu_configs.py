@@ -276,3 +276,22 @@ def test_logmel_kernel_clamp_cases(model, synth_sd):
     assert float((raw[1].cpu() - ref_raw[1]).abs()[strong].max()) < 0.02
     assert float((bn[1].cpu() - ref_bn[1]).abs()[strong].max()) < 5e-3
     assert float(raw[1].min()) >= -100.0 - 1e-4
+
+
+@pytest.mark.parametrize("B,L", [(1, 320000), (3, 96123), (20, 48000)])
+def test_wide_kernel_tile_shape_is_invisible(synth_sd, B, L, monkeypatch):
+    """The fused MLP of stages 1-2 runs 64-pixel tiles (one 16-pixel block per wave) when all of them find a CU at once and
+    128-pixel tiles otherwise (mlp_fused_wide.hip, launch_mlp_fused_wide): the arithmetic of a pixel does not depend on the tile
+    shape, so forcing either one (ACX_WIDE_NPB, read at every launch) must give the same bits -- and the default choice too."""
+    m = make_model(synth_sd, "fp32_split")
+    wav = synth.synth_waveforms(B, L, seed=900 + B).cuda()
+    outs = {}
+    for npb in ("1", "2", None):
+        if npb is None:
+            monkeypatch.delenv("ACX_WIDE_NPB", raising=False)
+        else:
+            monkeypatch.setenv("ACX_WIDE_NPB", npb)
+        outs[npb] = (m(wav)["clipwise_logits"].clone(), m.forward_frame_embeddings(wav).clone())
+        torch.cuda.synchronize()
+    for k in ("2", None):
+        assert torch.equal(outs[k][0], outs["1"][0]) and torch.equal(outs[k][1], outs["1"][1]), k
