@@ -337,10 +337,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
 //     for the next tile as soon as their half is done.  208 of the 256 registers: 96 accumulators, 64 + 48 fragments;
 //   * D = W A^T tile: lane l holds m = l & 15, n = 4 (l >> 4) .. + 3 -- again four consecutive n per lane (16-byte
 //     accesses); the two lanes l, l + 16 that share an S16 block of 8 n trade halves with v_permlane16_swap.
-template <int EPI, int GATHER>
+// MI = 16-row blocks per wave: 4 (256 x 192 tiles), or 2 / 1 (128 / 64 rows) for launches whose narrower tiles all find a CU at once
+// (small batches); an output element sees the same MFMAs in the same order whatever MI is
+template <int EPI, int GATHER, int MI>
 __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
-    constexpr int kBM = 256, BN = 192, WN = 2, NW = 8;
-    constexpr int MI = 4, NJ = 6;                                         // 16-row blocks of a wave's 64 x 96 tile
+    constexpr int kBM = 64 * MI, BN = 192, WN = 2, NW = 8;
+    constexpr int NJ = 6;                                                 // 16-row blocks of a wave's (16 MI) x 96 tile
+    static_assert(MI == 1 || MI == 2 || MI == 4, "rows per wave");
     constexpr int A_TILE = kBM * kSRowBytes, B_TILE = BN * kSRowBytes;
     constexpr int A_DMA = kBM / (8 * NW), B_DMA = BN / (8 * NW);          // 4 + 3 one-KB pieces per wave per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
     const int sw = acx_swz8(l15);
     const int foff_hi = l15 * kSRowBytes + (((2 * g4) ^ sw) << 4);
     const int foff_lo = l15 * kSRowBytes + (((2 * g4 + 1) ^ sw) << 4);
-    const int a_frag_off = wm * 64 * kSRowBytes;
+    const int a_frag_off = wm * (16 * MI) * kSRowBytes;
     const int b_frag_off = wn * 96 * kSRowBytes;
 #define ACX_H8(x) __builtin_bit_cast(h8, x)
 #define ACX_RD_A(F, abase)                                                                             \
@@ -457,8 +460,8 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
                 else if (pc < A_DMA + B_DMA)                                                           \
                     lds_dma16_s(a_src[pc - B_DMA] + (koffA), a_dst + (aslot) * A_TILE + (pc - B_DMA) * 8 * kSRowBytes); \
             }                                                                                          \
-            if (mc < 8) ANX[mc >> 1][mc & 1] = *reinterpret_cast<const f32x4*>((abn_) + (mc >> 1) * 16 * kSRowBytes + ((mc & 1) ? foff_lo : foff_hi)); \
-            else if (mc < 14) BLX[(mc - 8) >> 1][mc & 1] = *reinterpret_cast<const f32x4*>((bbn_) + ((mc - 8) >> 1) * 16 * kSRowBytes + ((mc & 1) ? foff_lo : foff_hi)); \
+            if (mc < 2 * MI) ANX[mc >> 1][mc & 1] = *reinterpret_cast<const f32x4*>((abn_) + (mc >> 1) * 16 * kSRowBytes + ((mc & 1) ? foff_lo : foff_hi)); \
+            else if (mc < 2 * MI + 6) BLX[(mc - 2 * MI) >> 1][mc & 1] = *reinterpret_cast<const f32x4*>((bbn_) + ((mc - 2 * MI) >> 1) * 16 * kSRowBytes + ((mc & 1) ? foff_lo : foff_hi)); \
             __builtin_amdgcn_sched_barrier(0);                                                         \
         } }
 #define ACX_DMA_A(koffA, aslot)                                                                        \
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
         char* outb = reinterpret_cast<char*>(p.out);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const long long m = m0 + wm * 64 + i * 16 + l15;
+            const long long m = m0 + wm * (16 * MI) + i * 16 + l15;
             const bool ok = m < p.M;
             char* orow = outb + (ok ? m : 0) * p.N * 4;
 #pragma unroll
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
         float* outf = reinterpret_cast<float*>(p.out);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const long long m = m0 + wm * 64 + i * 16 + l15;
+            const long long m = m0 + wm * (16 * MI) + i * 16 + l15;
             const bool ok = m < p.M;
             const long long row = (ok ? m : 0) * p.N;
             f32x4 rv[NJ];
@@ -595,19 +598,34 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
     }
 }
 
-template <int EPI, int GATHER>
+template <int EPI, int GATHER, int MI>
 static int launch_s16_cfg(const GemmSParams& p0, hipStream_t s) {
     GemmSParams p = p0;
     p.tiles_n = p.N / 192;
-    const long long tiles_m = (p.M + 255) / 256;
+    const long long tiles_m = (p.M + 64 * MI - 1) / (64 * MI);
     const long long blocks = tiles_m * p.tiles_n;
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm_split: grid too large");
     constexpr size_t lds = kCuLdsBytes;          // all of it: CU-exclusive
     static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &gemm_split16_kernel<EPI, GATHER>, lds));
-    gemm_split16_kernel<EPI, GATHER><<<dim3((unsigned)blocks), dim3(512), lds, s>>>(p);
+    ACX_TRY(set_max_dynamic_lds(once, &gemm_split16_kernel<EPI, GATHER, MI>, lds));
+    gemm_split16_kernel<EPI, GATHER, MI><<<dim3((unsigned)blocks), dim3(512), lds, s>>>(p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
+}
+// the narrowest row tile (64 / 128 / 256 rows) whose workgroups -- those of every sub-batch in flight -- all find a CU at once:
+// a small launch spreads over more CUs; beyond one round the 256-row tile is the efficient one.  ACX_GEMM_MI forces one (tests).
+template <int EPI, int GATHER>
+static int launch_s16_any(const GemmSParams& p, int ways, hipStream_t s) {
+    int cus = 0;
+    ACX_TRY(cu_count_of_current_device(&cus));
+    const long long tn = p.N / 192;
+    int mi = 4;
+    if ((p.M + 63) / 64 * tn * ways <= cus) mi = 1;
+    else if ((p.M + 127) / 128 * tn * ways <= cus) mi = 2;
+    if (const char* e = std::getenv("ACX_GEMM_MI")) mi = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : (e[0] == '4' ? 4 : mi));
+    if (mi == 1) return launch_s16_cfg<EPI, GATHER, 1>(p, s);
+    if (mi == 2) return launch_s16_cfg<EPI, GATHER, 2>(p, s);
+    return launch_s16_cfg<EPI, GATHER, 4>(p, s);
 }
 
 template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>
@@ -627,12 +645,12 @@ static int launch_s_cfg(const GemmSParams& p0, hipStream_t s) {
 }
 
 template <int EPI, int GATHER>
-static int launch_s_bn(const GemmSParams& p, hipStream_t s) {
+static int launch_s_bn(const GemmSParams& p, int ways, hipStream_t s) {
     // every N of the model (192, 384, 768, 1536, 3072) is a multiple of 192: 256 x 192 tiles -- 36 MFMAs per barrier and
     // the fewest operand bytes per flop through the LDS-DMA path; 256 x 128 for other multiples of 128
     if (p.N % 192 == 0) {
         static const bool old_shape = [] { const char* e = std::getenv("ACX_GEMM_32X32"); return e && e[0] == '1'; }();   // A/B switch
-        if ((p.K / kSBK) % 2 == 0 && !old_shape) return launch_s16_cfg<EPI, GATHER>(p, s);
+        if ((p.K / kSBK) % 2 == 0 && !old_shape) return launch_s16_any<EPI, GATHER>(p, ways, s);
         return launch_s_cfg<256, 192, 4, 2, EPI, GATHER>(p, s);
     }
     if (p.N % 128 == 0) return launch_s_cfg<256, 128, 4, 2, EPI, GATHER>(p, s);
@@ -647,13 +665,14 @@ int launch_gemm_split(acx_ctx* c, const GemmSplitArgs& a, hipStream_t s) {
     p.out = a.out; p.resid = a.resid; p.M = a.M; p.N = a.N; p.K = a.K; p.sinv = a.sinv; p.hscale = a.hscale;
     p.H = a.H; p.W = a.W; p.C = a.C; p.Ho = a.Ho; p.Wo = a.Wo; p.tiles_n = 0;
     ProfScope ps(c, a.cls, s);
+    const int ways = c && c->inflight_ways > 0 ? c->inflight_ways : 1;
     if (a.gather) {
         if (a.epi != EPI_BIAS || a.C % kSBK != 0) ACX_FAIL(ACX_ERR_ARG, "gemm_split: bad gather configuration");
-        return launch_s_bn<0, 1>(p, s);
+        return launch_s_bn<0, 1>(p, ways, s);
     }
-    if (a.epi == EPI_GELU) return launch_s_bn<1, 0>(p, s);
-    if (a.epi == EPI_RESID) return launch_s_bn<2, 0>(p, s);
-    if (a.epi == EPI_BIAS) return launch_s_bn<0, 0>(p, s);
+    if (a.epi == EPI_GELU) return launch_s_bn<1, 0>(p, ways, s);
+    if (a.epi == EPI_RESID) return launch_s_bn<2, 0>(p, ways, s);
+    if (a.epi == EPI_BIAS) return launch_s_bn<0, 0>(p, ways, s);
     ACX_FAIL(ACX_ERR_ARG, "gemm_split: unknown epilogue %d", a.epi);
 }
 

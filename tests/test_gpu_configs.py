@@ -279,19 +279,26 @@ def test_logmel_kernel_clamp_cases(model, synth_sd):
 
 
 @pytest.mark.parametrize("B,L", [(1, 320000), (3, 96123), (20, 48000)])
-def test_wide_kernel_tile_shape_is_invisible(synth_sd, B, L, monkeypatch):
-    """The fused MLP of stages 1-2 runs 64-pixel tiles (one 16-pixel block per wave) when all of them find a CU at once and
-    128-pixel tiles otherwise (mlp_fused_wide.hip, launch_mlp_fused_wide): the arithmetic of a pixel does not depend on the tile
-    shape, so forcing either one (ACX_WIDE_NPB, read at every launch) must give the same bits -- and the default choice too."""
+def test_small_launch_tile_shapes_are_invisible(synth_sd, B, L, monkeypatch):
+    """Small launches use narrower tiles so that they spread over more CUs: the fused MLP of stages 1-2 runs 64-pixel tiles (one
+    16-pixel block per wave) instead of 128 (mlp_fused_wide.hip, ACX_WIDE_NPB = 1 | 2), the split GEMM of stage 3 and of the
+    downsample convs 64- or 128-row tiles instead of 256 (gemm_split.hip, ACX_GEMM_MI = 1 | 2 | 4) -- whenever all the narrower
+    tiles find a CU at once.  The arithmetic of an output element does not depend on the tile shape: forcing any of them (the
+    variables are read at every launch) must give the same bits as the default choice."""
     m = make_model(synth_sd, "fp32_split")
     wav = synth.synth_waveforms(B, L, seed=900 + B).cuda()
-    outs = {}
-    for npb in ("1", "2", None):
-        if npb is None:
-            monkeypatch.delenv("ACX_WIDE_NPB", raising=False)
-        else:
-            monkeypatch.setenv("ACX_WIDE_NPB", npb)
-        outs[npb] = (m(wav)["clipwise_logits"].clone(), m.forward_frame_embeddings(wav).clone())
+
+    def run():
+        out = (m(wav)["clipwise_logits"].clone(), m.forward_frame_embeddings(wav).clone())
         torch.cuda.synchronize()
-    for k in ("2", None):
-        assert torch.equal(outs[k][0], outs["1"][0]) and torch.equal(outs[k][1], outs["1"][1]), k
+        return out
+
+    monkeypatch.delenv("ACX_WIDE_NPB", raising=False)
+    monkeypatch.delenv("ACX_GEMM_MI", raising=False)
+    ref = run()
+    for var, values in (("ACX_WIDE_NPB", ("1", "2")), ("ACX_GEMM_MI", ("1", "2", "4"))):
+        for v in values:
+            monkeypatch.setenv(var, v)
+            got = run()
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (var, v)
+        monkeypatch.delenv(var)
