@@ -8,6 +8,7 @@
 // the XOR swizzle on the source address, fragments double-buffered in registers, one barrier per k-tile.  A
 // fragment read is still one ds_read_b128: lane half h takes chunk 2g+h of its row = k 16g+8h .. +7, exactly
 // the A/B lane map of the 32x32x16 instruction, so one MFMA per (tile, k-group) replaces four fp32 ones.
+#include <cstdlib>
 #include "acx_internal.h"
 #include "split_math.h"
 
@@ -244,8 +245,17 @@ static int launch_bf_cfg(const GemmBfParams& p0, hipStream_t s) {
 }
 
 template <int EPI, int GATHER>
-static int launch_bf_bn(const GemmBfParams& p, hipStream_t s) {
-    if (p.N % 192 == 0) return launch_bf_cfg<256, 192, 4, 2, EPI, GATHER>(p, s);      // every N of the model
+static int launch_bf_bn(const GemmBfParams& p, int ways, hipStream_t s) {
+    if (p.N % 192 == 0) {                                                            // every N of the model
+        // 128-row tiles when all of them -- of every sub-batch in flight -- find a CU at once (small launches spread over twice the
+        // CUs; an output element sees the same MFMAs in the same order).  ACX_GEMM_MI = 1 | 2 forces them, 4 the 256-row tile.
+        int cus = 0;
+        ACX_TRY(cu_count_of_current_device(&cus));
+        bool narrow = (p.M + 127) / 128 * (p.N / 192) * ways <= cus;
+        if (const char* e = std::getenv("ACX_GEMM_MI")) narrow = e[0] == '4' ? false : ((e[0] == '1' || e[0] == '2') ? true : narrow);
+        if (narrow) return launch_bf_cfg<128, 192, 4, 2, EPI, GATHER>(p, s);
+        return launch_bf_cfg<256, 192, 4, 2, EPI, GATHER>(p, s);
+    }
     if (p.N % 128 == 0) return launch_bf_cfg<256, 128, 4, 2, EPI, GATHER>(p, s);
     ACX_FAIL(ACX_ERR_SHAPE, "gemm_bf16: N=%d is not a multiple of 192 or 128", p.N);
 }
@@ -258,14 +268,15 @@ int launch_gemm_bf16(acx_ctx* c, const GemmBf16Args& a, hipStream_t s) {
     p.out = a.out; p.resid = a.resid; p.M = a.M; p.N = a.N; p.Kp = a.Kp; p.lda = a.lda;
     p.H = a.H; p.W = a.W; p.Cp = a.Cp; p.Ho = a.Ho; p.Wo = a.Wo; p.tiles_n = 0;
     ProfScope ps(c, a.cls, s);
+    const int ways = c && c->inflight_ways > 0 ? c->inflight_ways : 1;
     if (a.gather) {
         if (a.epi != EPI_BIAS || a.Cp % kBfBK != 0) ACX_FAIL(ACX_ERR_ARG, "gemm_bf16: bad gather configuration");
-        return a.out_bf16 ? launch_bf_bn<3, 1>(p, s) : launch_bf_bn<0, 1>(p, s);
+        return a.out_bf16 ? launch_bf_bn<3, 1>(p, ways, s) : launch_bf_bn<0, 1>(p, ways, s);
     }
     if (a.out_bf16) ACX_FAIL(ACX_ERR_ARG, "gemm_bf16: bf16 output exists for the gather (downsample) form only");
-    if (a.epi == EPI_GELU) return launch_bf_bn<1, 0>(p, s);
-    if (a.epi == EPI_RESID) return launch_bf_bn<2, 0>(p, s);
-    if (a.epi == EPI_BIAS) return launch_bf_bn<0, 0>(p, s);
+    if (a.epi == EPI_GELU) return launch_bf_bn<1, 0>(p, ways, s);
+    if (a.epi == EPI_RESID) return launch_bf_bn<2, 0>(p, ways, s);
+    if (a.epi == EPI_BIAS) return launch_bf_bn<0, 0>(p, ways, s);
     ACX_FAIL(ACX_ERR_ARG, "gemm_bf16: unknown epilogue %d", a.epi);
 }
 

@@ -55,7 +55,7 @@ MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA, dense (no xf32 on gfx950)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA at the nominal 2.4 GHz
 # Shader clock the chip holds inside the split-fp16 MFMA kernels under load: 1.69 GHz stamped with s_memtime / s_memrealtime
 # in round 1's diagnostic builds (32x32x16 MFMAs), 1.94-2.11 GHz by GRBM_GUI_ACTIVE / duration in round 3's PMC passes of the
-# 16x16x32 kernels (profiles/r03_w_split_pmc_per_kernel.csv, r03_q_*: it differs box to box and falls as the loop gets tighter).
+# 16x16x32 kernels (profiles/r03_x_split_pmc_per_kernel.csv, r03_q_*: it differs box to box and falls as the loop gets tighter).
 # Reported next to `frac` as extra information; `peak` and `frac` themselves stay on the nominal 2.4 GHz figure.
 SPLIT_SHADER_CLOCK_GHZ = 1.95
 DIMS, DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)

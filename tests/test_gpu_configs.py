@@ -278,14 +278,16 @@ def test_logmel_kernel_clamp_cases(model, synth_sd):
     assert float(raw[1].min()) >= -100.0 - 1e-4
 
 
+@pytest.mark.parametrize("precision", ["fp32_split", "bf16a"])
 @pytest.mark.parametrize("B,L", [(1, 320000), (3, 96123), (20, 48000)])
-def test_small_launch_tile_shapes_are_invisible(synth_sd, B, L, monkeypatch):
+def test_small_launch_tile_shapes_are_invisible(synth_sd, B, L, precision, monkeypatch):
     """Small launches use narrower tiles so that they spread over more CUs: the fused MLP of stages 1-2 runs 64-pixel tiles (one
     16-pixel block per wave) instead of 128 (mlp_fused_wide.hip, ACX_WIDE_NPB = 1 | 2), the split GEMM of stage 3 and of the
     downsample convs 64- or 128-row tiles instead of 256 (gemm_split.hip, ACX_GEMM_MI = 1 | 2 | 4) -- whenever all the narrower
     tiles find a CU at once.  The arithmetic of an output element does not depend on the tile shape: forcing any of them (the
-    variables are read at every launch) must give the same bits as the default choice."""
-    m = make_model(synth_sd, "fp32_split")
+    variables are read at every launch) must give the same bits as the default choice.  (bf16 arithmetics: the GEMM switch
+    selects 128- against 256-row tiles of gemm_bf16_kernel; the fused bf16 kernels have one tile shape.)"""
+    m = make_model(synth_sd, precision)
     wav = synth.synth_waveforms(B, L, seed=900 + B).cuda()
 
     def run():
