@@ -524,9 +524,9 @@ __global__ __launch_bounds__(256, 2) void dwconv7_tile_kernel(const void* __rest
                                                               const float* __restrict__ bias, int H, int C, int tiles_h) {
     using Cfg = DwTileCfg<W, BF>;
     using T = typename std::conditional<BF, __bf16, float>::type;
-    constexpr int kCols = Cfg::kCols, kRowBytes = Cfg::kRowBytes, kIn = Cfg::kRows + 6;
+    constexpr int kRowBytes = Cfg::kRowBytes, kIn = Cfg::kRows + 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* img = smem;                                                           // [kIn][kCols][32] fp32, rows kRowBytes apart
+    char* img = smem;                                                           // [kIn][Cfg::kCols][32] fp32, rows kRowBytes apart
     f32x4* wl = reinterpret_cast<f32x4*>(smem + kIn * kRowBytes);               // [49][8]
     const int slices = C / kDwSlice;
     int bid = blockIdx.x;
