@@ -161,7 +161,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s) {
     long long nframes = (long long)B * T;
     long long blocks = (nframes + kFrontWaves - 1) / kFrontWaves;
-    if (blocks > 4096) blocks = 4096;
+    // 6 workgroups per CU (3 resident): a workgroup's setup -- twiddle and mel tables into the LDS, lane twiddles into registers --
+    // is paid once per ~10 frames of a wave (with 4 096 workgroups it was once per 4: 184 -> 167 us at B = 64)
+    if (blocks > 1536) blocks = 1536;
     ProfScope ps(c, ACX_K_FRONTEND, s);
     logmel_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(wav, L, T, nframes, c->d_hann, c->d_twiddle,
                                                                 c->d_mel_start, c->d_mel_len, c->d_mel_off,
