@@ -42,6 +42,7 @@ SIGNATURES = {
     "acx_downsample": (_c_int, [_vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "acx_pool_head": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp]),
     "acx_nhwc_to_nchw": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "acx_tuning_refresh": (_c_int, []),
     "acx_profile_enable": (_c_int, [_vp, _c_int]),
     "acx_profile_read": (_c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64)]),
 }

@@ -182,12 +182,14 @@ struct acx_ctx {
     // an HBM-bound kernel of one half fills the matrix-pipe-bound phases of the other and vice versa
     bool split_streams = true;    // ACX_SPLIT_STREAMS=0 turns it off
     int split_ways = 0;           // ACX_SPLIT_WAYS=n forces n sub-batches (1 .. kMaxSplitWays); 0: the per-arithmetic default
-    int inflight_ways = 1;       // sub-batches of the forward being queued (acx_forward): tile-shape choices of small launches see the others
     // fork/join resources per CALLER stream: forwards issued on different streams (or threads) never share an event.
-    // Sub-batch 0 runs on the caller's stream, sub-batch i > 0 on streams[i - 1].
+    // Sub-batch 0 runs on the caller's stream, sub-batch i > 0 on streams[i - 1].  An entry is pinned (users > 0) while a
+    // forward is queueing work on it; the map is bounded by dropping the least recently used UNPINNED entry.
     static constexpr int kMaxSplitWays = 4;
     struct Aux { hipStream_t streams[kMaxSplitWays - 1] = {}; hipEvent_t fork = nullptr, joins[kMaxSplitWays - 1] = {}; };
-    std::map<hipStream_t, Aux> aux;
+    struct AuxEntry { Aux a; unsigned long long stamp = 0; int users = 0; };
+    std::map<hipStream_t, AuxEntry> aux;
+    unsigned long long aux_clock = 0;
     std::mutex aux_mutex;
     // identity affine for acx_logmel_bn0(apply_bn0 = 0) (tests): per context, i.e. per device
     float* d_bn_one = nullptr;
@@ -196,6 +198,24 @@ struct acx_ctx {
 };
 
 namespace acx {
+
+// Sub-batches of the forward THIS THREAD is queueing (acx_forward): the tile-shape choice of a small launch counts the
+// workgroups of the other sub-batches too.  Per thread, not per context: concurrent forwards on one context from several
+// host threads are supported and must not race on it.
+extern thread_local int tls_inflight_ways;
+inline int inflight_ways() { return tls_inflight_ways > 0 ? tls_inflight_ways : 1; }
+
+// Diagnostic A/B switches (tile shape overrides), read from the environment ONCE (first acx_create) and again only through
+// acx_tuning_refresh() (tests): launches read these atomics, never the environment (an uncached getenv scan sat on the
+// batch-1 latency path and is not safe beside a setenv in another thread).
+struct Tuning {
+    std::atomic<int> gemm_mi{0};       // ACX_GEMM_MI = 1 | 2 | 4: row blocks per wave of the split / bf16 GEMM tiles (0: by launch size)
+    std::atomic<int> wide_npb{0};      // ACX_WIDE_NPB = 1 | 2: pixel blocks per wave of the wide fused MLP (0: by launch size)
+    std::atomic<int> gemm_32x32{0};    // ACX_GEMM_32X32 = 1: the 32x32x16 form of the split GEMM
+    std::atomic<int> dw_stream{-1};    // ACX_DW_STREAM = 0 | 1: forces the tile / column-streaming depthwise kernels (-1: by launch size)
+};
+Tuning& tuning();
+void tuning_reload();
 
 struct ProfScope {       // records a HIP-event pair around a launch when profiling is on
     acx_ctx* ctx; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;

@@ -10,6 +10,24 @@
 namespace acx {
 
 static thread_local char g_err[512] = "";
+thread_local int tls_inflight_ways = 1;
+
+Tuning& tuning() {
+    static Tuning t;
+    return t;
+}
+void tuning_reload() {
+    auto digit = [](const char* name, const char* allowed, int none) {
+        const char* e = std::getenv(name);
+        if (!e || !e[0] || e[1] || !std::strchr(allowed, e[0])) return none;
+        return e[0] - '0';
+    };
+    Tuning& t = tuning();
+    t.gemm_mi.store(digit("ACX_GEMM_MI", "124", 0), std::memory_order_relaxed);
+    t.wide_npb.store(digit("ACX_WIDE_NPB", "12", 0), std::memory_order_relaxed);
+    t.gemm_32x32.store(digit("ACX_GEMM_32X32", "1", 0), std::memory_order_relaxed);
+    t.dw_stream.store(digit("ACX_DW_STREAM", "01", -1), std::memory_order_relaxed);
+}
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -647,10 +665,14 @@ int acx_create(int hip_device, acx_ctx** out) {
         if (e2 && e2[0] >= '1' && e2[0] <= '0' + acx_ctx::kMaxSplitWays && e2[1] == 0) c->split_ways = e2[0] - '0';
     }
     {   // the null stream's side stream + events exist from the start (nothing is created inside a capture)
-        acx_ctx::Aux a;
-        int rc = make_aux(&a);
+        acx_ctx::AuxEntry e;
+        int rc = make_aux(&e.a);
         if (rc != ACX_OK) { delete c; return rc; }
-        c->aux.emplace((hipStream_t) nullptr, a);
+        c->aux.emplace((hipStream_t) nullptr, e);
+    }
+    {
+        static std::once_flag env_once;
+        std::call_once(env_once, tuning_reload);
     }
     *out = c;
     return ACX_OK;
@@ -662,7 +684,7 @@ void acx_destroy(acx_ctx* c) {
     free_device(c);
     for (auto& r : c->prof.recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
-    for (auto& kv : c->aux) destroy_aux(kv.second);
+    for (auto& kv : c->aux) destroy_aux(kv.second.a);
     delete c;
 }
 
@@ -757,27 +779,42 @@ int acx_sub_batches(const acx_ctx* c, int B, int* out) {
 }
 
 static constexpr size_t kMaxAuxStreams = 16;
-static int get_aux(acx_ctx* c, hipStream_t st, acx_ctx::Aux* out) {
+// The fork/join set of caller stream `st`, pinned until release_aux().  *found = false (and nothing pinned) when the stream
+// has no set yet and one cannot be made now -- the first split forward on the stream happens inside a stream capture
+// (hipStreamCreate is illegal there; `with torch.cuda.graph(g): model(x)` captures on a private stream nobody can warm
+// up): the caller then runs the batch un-split, which gives the same bits.
+static int get_aux(acx_ctx* c, hipStream_t st, acx_ctx::Aux* out, bool* found) {
     std::lock_guard<std::mutex> lock(c->aux_mutex);
+    *found = false;
     auto it = c->aux.find(st);
     if (it == c->aux.end()) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-            ACX_FAIL(ACX_ERR_STATE, "first split forward on this stream happens inside a stream capture: run one forward on "
-                                    "the stream before capturing (the side stream and its events are created then)");
-        acx_ctx::Aux a;
-        ACX_TRY(make_aux(&a));
-        if (c->aux.size() >= kMaxAuxStreams) {          // drop a set that is not the null stream's
+        if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return ACX_OK;
+        acx_ctx::AuxEntry e;
+        ACX_TRY(make_aux(&e.a));
+        if (c->aux.size() >= kMaxAuxStreams) {          // drop the least recently used set nobody is queueing on
+            auto victim = c->aux.end();
             for (auto d = c->aux.begin(); d != c->aux.end(); ++d)
-                if (d->first != nullptr) {
-                    for (auto sd : d->second.streams) if (sd) (void)hipStreamSynchronize(sd);
-                    destroy_aux(d->second); c->aux.erase(d); break;
-                }
+                if (d->first != nullptr && d->second.users == 0 && (victim == c->aux.end() || d->second.stamp < victim->second.stamp))
+                    victim = d;
+            if (victim != c->aux.end()) {
+                for (auto sd : victim->second.a.streams) if (sd) (void)hipStreamSynchronize(sd);
+                destroy_aux(victim->second.a);
+                c->aux.erase(victim);
+            }
         }
-        it = c->aux.emplace(st, a).first;
+        it = c->aux.emplace(st, e).first;
     }
-    *out = it->second;
+    it->second.stamp = ++c->aux_clock;
+    it->second.users += 1;
+    *out = it->second.a;
+    *found = true;
     return ACX_OK;
+}
+static void release_aux(acx_ctx* c, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(c->aux_mutex);
+    auto it = c->aux.find(st);
+    if (it != c->aux.end() && it->second.users > 0) it->second.users -= 1;
 }
 
 static int forward_one(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float* out0, float* out1, char* ws,
@@ -829,33 +866,46 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
     // shares a CU with them -- but a second stream's workgroups take the CUs their tail rounds and launch boundaries
     // leave idle: +4 % (fp32_split) / +11 % (bf16a) at B = 64.
     const int ways = split_ways_for(c, B);
-    if (ways > 1) {
-        acx_ctx::Aux aux;
-        ACX_TRY(get_aux(c, st, &aux));
-        ACX_HIP(hipEventRecord(aux.fork, st));
+    acx_ctx::Aux aux;
+    bool have_aux = false;
+    if (ways > 1) ACX_TRY(get_aux(c, st, &aux, &have_aux));
+    if (ways > 1 && have_aux) {
+        // From here on every exit joins the side streams that were forked (an error in sub-batch i must not leave an
+        // un-joined fork behind -- inside a stream capture that invalidates the capture, and the caller may free the
+        // workspace the side streams still use) and unpins the set.
+        int rc = ACX_OK;
+        int forked = 0;                 // side streams that wait on the fork event so far
+        hipError_t he = hipEventRecord(aux.fork, st);
+        if (he != hipSuccess) { set_error("hipEventRecord(fork) failed: %s", hipGetErrorString(he)); rc = ACX_ERR_HIP; }
         size_t ws_off = 0;
         int b_off = 0;
-        for (int i = 0; i < ways; ++i) {
+        tls_inflight_ways = ways;
+        for (int i = 0; i < ways && rc == ACX_OK; ++i) {
             const int Bi = split_part(B, ways, i);
             Plan pi;
-            ACX_TRY(make_plan(Bi, L, &pi));
+            rc = make_plan(Bi, L, &pi);
+            if (rc != ACX_OK) break;
             const size_t per_clip = mode == ACX_MODE_FRAME ? (size_t)kDims[3] * pi.Hs[3] * pi.Ws[3]
                                                            : (mode == ACX_MODE_SCENE ? (size_t)kDims[3] : (size_t)kClasses);
             hipStream_t si = i == 0 ? st : aux.streams[i - 1];
-            if (i > 0) ACX_HIP(hipStreamWaitEvent(si, aux.fork, 0));
-            c->inflight_ways = ways;
-            const int rc = forward_one(c, wav + (size_t)b_off * L, Bi, L, mode, out0 + b_off * per_clip,
-                                       out1 ? out1 + b_off * per_clip : nullptr, ws + ws_off, pi, si);
-            c->inflight_ways = 1;
-            if (rc != ACX_OK) return rc;
             if (i > 0) {
-                ACX_HIP(hipEventRecord(aux.joins[i - 1], si));
-                ACX_HIP(hipStreamWaitEvent(st, aux.joins[i - 1], 0));
+                he = hipStreamWaitEvent(si, aux.fork, 0);
+                if (he != hipSuccess) { set_error("hipStreamWaitEvent(fork) failed: %s", hipGetErrorString(he)); rc = ACX_ERR_HIP; break; }
+                forked = i;
             }
+            rc = forward_one(c, wav + (size_t)b_off * L, Bi, L, mode, out0 + b_off * per_clip,
+                             out1 ? out1 + b_off * per_clip : nullptr, ws + ws_off, pi, si);
             ws_off += pi.total;
             b_off += Bi;
         }
-        return ACX_OK;
+        tls_inflight_ways = 1;
+        for (int i = 1; i <= forked; ++i) {            // join whatever was forked, also after an error
+            hipError_t e1 = hipEventRecord(aux.joins[i - 1], aux.streams[i - 1]);
+            if (e1 == hipSuccess) e1 = hipStreamWaitEvent(st, aux.joins[i - 1], 0);
+            if (e1 != hipSuccess && rc == ACX_OK) { set_error("joining sub-batch %d failed: %s", i, hipGetErrorString(e1)); rc = ACX_ERR_HIP; }
+        }
+        release_aux(c, st);
+        return rc;
     }
     Plan p;
     ACX_TRY(make_plan(B, L, &p));
@@ -931,6 +981,11 @@ int acx_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float
 int acx_nhwc_to_nchw(const float* x, float* out, int B, int H, int Wd, int C, void* stream) {
     if (!x || !out || B <= 0 || H <= 0 || Wd <= 0 || C <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_nhwc_to_nchw: bad argument");
     return launch_nhwc_to_nchw(nullptr, x, out, B, H, Wd, C, (hipStream_t)stream);
+}
+
+int acx_tuning_refresh(void) {
+    tuning_reload();
+    return ACX_OK;
 }
 
 int acx_profile_enable(acx_ctx* c, int on) {

@@ -252,7 +252,7 @@ static int launch_bf_bn(const GemmBfParams& p, int ways, hipStream_t s) {
         int cus = 0;
         ACX_TRY(cu_count_of_current_device(&cus));
         bool narrow = (p.M + 127) / 128 * (p.N / 192) * ways <= cus;
-        if (const char* e = std::getenv("ACX_GEMM_MI")) narrow = e[0] == '4' ? false : ((e[0] == '1' || e[0] == '2') ? true : narrow);
+        if (const int f = tuning().gemm_mi.load(std::memory_order_relaxed)) narrow = f != 4;
         if (narrow) return launch_bf_cfg<128, 192, 4, 2, EPI, GATHER>(p, s);
         return launch_bf_cfg<256, 192, 4, 2, EPI, GATHER>(p, s);
     }
@@ -268,7 +268,7 @@ int launch_gemm_bf16(acx_ctx* c, const GemmBf16Args& a, hipStream_t s) {
     p.out = a.out; p.resid = a.resid; p.M = a.M; p.N = a.N; p.Kp = a.Kp; p.lda = a.lda;
     p.H = a.H; p.W = a.W; p.Cp = a.Cp; p.Ho = a.Ho; p.Wo = a.Wo; p.tiles_n = 0;
     ProfScope ps(c, a.cls, s);
-    const int ways = c && c->inflight_ways > 0 ? c->inflight_ways : 1;
+    const int ways = inflight_ways();
     if (a.gather) {
         if (a.epi != EPI_BIAS || a.Cp % kBfBK != 0) ACX_FAIL(ACX_ERR_ARG, "gemm_bf16: bad gather configuration");
         return a.out_bf16 ? launch_bf_bn<3, 1>(p, ways, s) : launch_bf_bn<0, 1>(p, ways, s);

@@ -622,7 +622,7 @@ static int launch_s16_any(const GemmSParams& p, int ways, hipStream_t s) {
     int mi = 4;
     if ((p.M + 63) / 64 * tn * ways <= cus) mi = 1;
     else if ((p.M + 127) / 128 * tn * ways <= cus) mi = 2;
-    if (const char* e = std::getenv("ACX_GEMM_MI")) mi = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : (e[0] == '4' ? 4 : mi));
+    if (const int f = tuning().gemm_mi.load(std::memory_order_relaxed)) mi = f;
     if (mi == 1) return launch_s16_cfg<EPI, GATHER, 1>(p, s);
     if (mi == 2) return launch_s16_cfg<EPI, GATHER, 2>(p, s);
     return launch_s16_cfg<EPI, GATHER, 4>(p, s);
@@ -649,7 +649,7 @@ static int launch_s_bn(const GemmSParams& p, int ways, hipStream_t s) {
     // every N of the model (192, 384, 768, 1536, 3072) is a multiple of 192: 256 x 192 tiles -- 36 MFMAs per barrier and
     // the fewest operand bytes per flop through the LDS-DMA path; 256 x 128 for other multiples of 128
     if (p.N % 192 == 0) {
-        static const bool old_shape = [] { const char* e = std::getenv("ACX_GEMM_32X32"); return e && e[0] == '1'; }();   // A/B switch
+        const bool old_shape = tuning().gemm_32x32.load(std::memory_order_relaxed) == 1;   // A/B switch
         if ((p.K / kSBK) % 2 == 0 && !old_shape) return launch_s16_any<EPI, GATHER>(p, ways, s);
         return launch_s_cfg<256, 192, 4, 2, EPI, GATHER>(p, s);
     }
@@ -665,7 +665,7 @@ int launch_gemm_split(acx_ctx* c, const GemmSplitArgs& a, hipStream_t s) {
     p.out = a.out; p.resid = a.resid; p.M = a.M; p.N = a.N; p.K = a.K; p.sinv = a.sinv; p.hscale = a.hscale;
     p.H = a.H; p.W = a.W; p.C = a.C; p.Ho = a.Ho; p.Wo = a.Wo; p.tiles_n = 0;
     ProfScope ps(c, a.cls, s);
-    const int ways = c && c->inflight_ways > 0 ? c->inflight_ways : 1;
+    const int ways = inflight_ways();
     if (a.gather) {
         if (a.epi != EPI_BIAS || a.C % kSBK != 0) ACX_FAIL(ACX_ERR_ARG, "gemm_split: bad gather configuration");
         return launch_s_bn<0, 1>(p, ways, s);

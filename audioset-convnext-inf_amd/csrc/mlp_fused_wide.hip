@@ -542,9 +542,9 @@ int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, fl
     // The arithmetic of a pixel does not depend on the choice (same MFMA order, same GELU): results are bit-identical.
     int cus = 0;
     ACX_TRY(cu_count_of_current_device(&cus));
-    const int ways = c && c->inflight_ways > 0 ? c->inflight_ways : 1;
+    const int ways = inflight_ways();
     bool half = (M + 63) / 64 * ways <= cus;
-    if (const char* e = std::getenv("ACX_WIDE_NPB")) half = e[0] == '1' ? true : (e[0] == '2' ? false : half);
+    if (const int f = tuning().wide_npb.load(std::memory_order_relaxed)) half = f == 1;
 #define ACX_GO(C_, LN_) (half ? launch_wide_cfg<C_, 1, LN_, 1>(w, y, x, M, LN_ ? ln_out : nullptr, s) : launch_wide_cfg<C_, 1, LN_, 2>(w, y, x, M, LN_ ? ln_out : nullptr, s))
     if (C == 384) return ln_out ? ACX_GO(384, true) : ACX_GO(384, false);
     if (C == 192) return ln_out ? ACX_GO(192, true) : ACX_GO(192, false);

@@ -148,13 +148,33 @@ class ConvNeXt(nn.Module):
 
     # ------------------------------------------------------------------------------ native side
     def _signature(self):
-        """Changes whenever the weights may have: the epoch counter (load_state_dict / _apply / refresh) plus every tensor's
-        storage address and autograd version.  The tensor list is cached per epoch -- state_dict() builds 190 prefixed keys
-        and cost 0.6 ms per forward, ten times the rest of the host path at batch 1 (profiles/r03_f_latency_bs1.txt)."""
-        c = self._sig_cache
-        if c is None or c[0] != self._weights_epoch:
-            c = self._sig_cache = (self._weights_epoch, list(self.state_dict(keep_vars=True).values()))
-        return (self.precision, self._weights_epoch) + tuple((t.data_ptr(), t._version) for t in c[1])
+        """Changes whenever the weights may have: the epoch counter (load_state_dict / _apply / refresh) plus, for every
+        parameter and buffer, its identity, storage address and autograd version, plus the identity of every submodule.
+        What is cached per epoch is the list of the modules' own `_parameters` / `_buffers` / `_modules` dicts, not the
+        tensors: a replaced Parameter (`m.head_audioset.weight = nn.Parameter(...)`) shows up as a new id in its module's
+        dict, a replaced submodule (`m.head_audioset = nn.Linear(...)`) as a new child id in its parent's -- the latter
+        also rebuilds the cached list.  state_dict() itself builds 190 prefixed keys and cost 0.6 ms per
+        forward, ten times the rest of the host path at batch 1 (profiles/r03_f_latency_bs1.txt); this walk costs ~50 us."""
+        for _ in range(2):
+            c = self._sig_cache
+            if c is None or c[0] != self._weights_epoch:
+                dicts = [(m._parameters, m._buffers, m._modules) for m in self.modules()]
+                c = self._sig_cache = (self._weights_epoch, dicts,
+                                       tuple(id(x) for _, _, ch in dicts for x in ch.values()))
+            sig = [self.precision, self._weights_epoch]
+            kids = []
+            for params, bufs, children in c[1]:
+                for t in params.values():
+                    if t is not None:
+                        sig += (id(t), t.data_ptr(), t._version)
+                for t in bufs.values():
+                    if t is not None:
+                        sig += (id(t), t.data_ptr(), t._version)
+                kids += [id(x) for x in children.values()]
+            if tuple(kids) == c[2]:
+                return tuple(sig)
+            self._weights_epoch += 1        # the module tree changed: walk it again
+        raise RuntimeError("module tree changed while its signature was taken")
 
     def refresh(self):
         """Call after editing weights in a way autograd's version counters cannot see (`param.data.mul_(...)`, writes

@@ -29,13 +29,15 @@ class _Stager(object):
     multi-threaded copy: numpy releases the GIL), `to_device` in the caller: an asynchronous copy on its own stream, beside
     the model's work on the previous batch.  int16 batches (data_generator.evaluate_batches(device_cast=True)) cross PCIe as
     they are and become float32 on the GPU by the arithmetic of utilities.int16_to_float32 (/32767 in double precision,
-    one rounding to float32); float32 batches are copied as they are.  A buffer is rewritten three batches later, after
-    forward() has fetched the outputs of the batch that used it."""
+    one rounding to float32); float32 batches are copied as they are.  A buffer comes up for rewriting three batches later;
+    `to_pinned` first waits for the event recorded behind the asynchronous copy that last READ it (with a warm
+    model and fast page-cache reads nothing else orders the reader thread behind that DMA)."""
     kCopyThreads = 4
 
     def __init__(self, device):
         self.device = device
         self.pinned = [None, None, None]
+        self.ready = [None, None, None]     # per buffer: event behind the H2D copy that read it last
         self.turn = 0
         self.copy_stream = None
         self.pool = None
@@ -47,11 +49,16 @@ class _Stager(object):
     def to_pinned(self, x):
         x = np.asarray(x)
         n = x.size
-        buf = self.pinned[self.turn]
+        slot = self.turn
+        buf = self.pinned[slot]
+        ev = self.ready[slot]
+        if ev is not None:                  # the copy engine may still be reading this buffer
+            ev.synchronize()
+            self.ready[slot] = None
         want = torch.int16 if x.dtype == np.int16 else torch.float32
         if buf is None or buf.dtype != want or buf.numel() < n:
             buf = torch.empty(n, dtype=want).pin_memory()
-            self.pinned[self.turn] = buf
+            self.pinned[slot] = buf
         self.turn = (self.turn + 1) % 3
         host = buf[:n].view(x.shape)
         dst = host.numpy()
@@ -61,9 +68,10 @@ class _Stager(object):
         rows = x.shape[0]
         step = (rows + self.kCopyThreads - 1) // self.kCopyThreads
         list(self.pool.map(lambda r0: np.copyto(dst[r0:r0 + step], x[r0:r0 + step]), range(0, rows, step)))
-        return host
+        return host, slot
 
-    def to_device(self, host):
+    def to_device(self, staged):
+        host, slot = staged
         if self.copy_stream is None:
             self.copy_stream = torch.cuda.Stream(self.device)
         compute = torch.cuda.current_stream(self.device)
@@ -71,6 +79,7 @@ class _Stager(object):
             dev = host.to(self.device, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
+        self.ready[slot] = ready
         compute.wait_event(ready)
         dev.record_stream(compute)
         if dev.dtype == torch.int16:
@@ -92,25 +101,39 @@ def _ahead(generator, prepare, depth=1):
     import threading
     q = queue.Queue(maxsize=depth)
     done = object()
+    stop = threading.Event()            # set when the consumer leaves early (exception, break, generator closed)
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def work():
         try:
             for item in generator:
-                q.put((item, prepare(item)))
-            q.put(done)
+                if not put((item, prepare(item))):
+                    return
+            put(done)
         except BaseException as e:      # noqa: B902 -- handed to the consumer
-            q.put(e)
+            put(e)
 
     t = threading.Thread(target=work, daemon=True)
     t.start()
-    while True:
-        item = q.get()
-        if item is done:
-            break
-        if isinstance(item, BaseException):
-            raise item
-        yield item
-    t.join()
+    try:
+        while True:
+            item = q.get()
+            if item is done:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+        t.join(timeout=10)
 
 
 def forward(model, generator, return_input=False, return_target=False):

@@ -60,8 +60,10 @@ enum acx_mode {
 enum acx_precision {
     ACX_PREC_F32 = 0,         /* v_mfma_f32_32x32x2_f32: fp32 operands on the matrix cores */
     ACX_PREC_BF16 = 1,        /* bf16 operands, fp32 accumulate (NOT within the 1e-3 bar) */
-    ACX_PREC_F32_SPLIT = 2,   /* DEFAULT.  fp32 operands carried as fp16 hi + fp16 lo (24 significant bits), three fp16
-                               * MFMAs per product, fp32 accumulate: fp32-grade results (same parity tests and
+    ACX_PREC_F32_SPLIT = 2,   /* DEFAULT.  fp32 operands carried as fp16 hi + fp16 lo -- v = hi + lo + e with
+                               * |e| <= 2^-23 |v| in the worst case (exact for ~75 % of values; 22-23 significant bits
+                               * where fp32 has 24) -- three fp16 MFMAs per product (the lo*lo term, <= 2^-22 |ab|, is
+                               * dropped), fp32 accumulate: fp32-grade results (same parity tests and
                                * tolerances as ACX_PREC_F32, plus tests/test_gpu_stress.py) at 16/3 of the f32-MFMA
                                * rate.  Its kernels launch CU-exclusive workgroups (whole LDS + whole register file of
                                * a CU): work of other streams or processes never shares a CU with them. */
@@ -125,7 +127,9 @@ ACX_API int acx_workspace_bytes(const acx_ctx* ctx, int B, int64_t L, int mode, 
 /* How acx_forward runs a batch of B clips: as *out sub-batches side by side on separate streams (clips are independent in
  * eval mode, convnext.py:219,305 -- BatchNorm uses running statistics; every clip's result is bit-identical however the
  * batch is composed or split).  1 for small batches, while per-kernel profiling is enabled, or with ACX_SPLIT_STREAMS=0;
- * ACX_SPLIT_WAYS=n (1..4) overrides the default of 2.  No reference counterpart: torch runs one batch on one stream. */
+ * ACX_SPLIT_WAYS=n (1..4) overrides the default of 2.  A forward whose FIRST use of a caller stream happens inside a
+ * stream capture (`with torch.cuda.graph(g): model(x)` captures on a private stream) runs un-split -- the side streams
+ * cannot be created there -- with the same bits.  No reference counterpart: torch runs one batch on one stream. */
 ACX_API int acx_sub_batches(const acx_ctx* ctx, int B, int* out);
 
 /* The hot path.  wav: device (B, L) fp32.
@@ -167,6 +171,11 @@ ACX_API int acx_pool_head(acx_ctx* ctx, const float* x, int B, int H3, float* sc
                   float* probs, void* stream);
 /* NHWC -> NCHW (the layout forward_frame_embeddings returns, convnext.py:276-277). */
 ACX_API int acx_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, void* stream);
+
+/* Diagnostics.  The tile-shape A/B switches ACX_GEMM_MI, ACX_WIDE_NPB, ACX_GEMM_32X32 and ACX_DW_STREAM are read from the
+ * environment once, at the first acx_create; this re-reads them (tests force every tile shape through it and require
+ * bit-identical results).  Launches never touch the environment.  No reference counterpart. */
+ACX_API int acx_tuning_refresh(void);
 
 /* ---- measurement: per-kernel-class device time, HIP events on the launch stream ------------ */
 ACX_API int acx_profile_enable(acx_ctx* ctx, int on);

@@ -285,7 +285,7 @@ def test_small_launch_tile_shapes_are_invisible(synth_sd, B, L, precision, monke
     16-pixel block per wave) instead of 128 (mlp_fused_wide.hip, ACX_WIDE_NPB = 1 | 2), the split GEMM of stage 3 and of the
     downsample convs 64- or 128-row tiles instead of 256 (gemm_split.hip, ACX_GEMM_MI = 1 | 2 | 4) -- whenever all the narrower
     tiles find a CU at once.  The arithmetic of an output element does not depend on the tile shape: forcing any of them (the
-    variables are read at every launch) must give the same bits as the default choice.  (bf16 arithmetics: the GEMM switch
+    variables are re-read by acx_tuning_refresh) must give the same bits as the default choice.  (bf16 arithmetics: the GEMM switch
     selects 128- against 256-row tiles of gemm_bf16_kernel; the fused bf16 kernels have one tile shape.)"""
     m = make_model(synth_sd, precision)
     wav = synth.synth_waveforms(B, L, seed=900 + B).cuda()
@@ -295,12 +295,21 @@ def test_small_launch_tile_shapes_are_invisible(synth_sd, B, L, precision, monke
         torch.cuda.synchronize()
         return out
 
-    monkeypatch.delenv("ACX_WIDE_NPB", raising=False)
-    monkeypatch.delenv("ACX_GEMM_MI", raising=False)
+    from audioset_convnext_inf_amd import _ffi
+    refresh = _ffi.lib().acx_tuning_refresh
+    for var in ("ACX_WIDE_NPB", "ACX_GEMM_MI", "ACX_DW_STREAM"):
+        monkeypatch.delenv(var, raising=False)
+    refresh()
     ref = run()
-    for var, values in (("ACX_WIDE_NPB", ("1", "2")), ("ACX_GEMM_MI", ("1", "2", "4"))):
-        for v in values:
-            monkeypatch.setenv(var, v)
-            got = run()
-            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (var, v)
-        monkeypatch.delenv(var)
+    try:
+        for var, values in (("ACX_WIDE_NPB", ("1", "2")), ("ACX_GEMM_MI", ("1", "2", "4")), ("ACX_DW_STREAM", ("0", "1"))):
+            for v in values:
+                monkeypatch.setenv(var, v)
+                refresh()
+                got = run()
+                assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (var, v)
+            monkeypatch.delenv(var)
+    finally:
+        for var in ("ACX_WIDE_NPB", "ACX_GEMM_MI", "ACX_DW_STREAM"):
+            monkeypatch.delenv(var, raising=False)
+        refresh()

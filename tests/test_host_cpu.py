@@ -168,3 +168,38 @@ def test_bench_self_launch_dry_run():
                        env=dict(env, ACX_BENCH_DRYRUN_FAIL_RANK="1"))
     assert r.returncode == 1 and "rank 1 failed first" in r.stderr, r.stderr[-800:]
     assert time.time() - t0 < 120
+
+
+def test_weight_signature_sees_replaced_parameters_and_submodules():
+    """the per-epoch cache behind ConvNeXt._signature() must not hide a replaced Parameter or submodule
+    (the native context would go on running the old packed weights), nor later in-place edits of the new tensors."""
+    import torch.nn as nn
+    m = convnext_tiny(after_stem_dim=[252, 56]).eval()
+    s0 = m._signature()
+    assert m._signature() == s0                                   # stable while nothing changes
+    m.head_audioset.weight = nn.Parameter(torch.zeros(527, 768))  # parameter of a SUBmodule replaced
+    s1 = m._signature()
+    assert s1 != s0
+    with torch.no_grad():
+        m.head_audioset.weight.add_(1.0)                          # in-place edit of the NEW tensor
+    s2 = m._signature()
+    assert s2 != s1
+    m.head_audioset = nn.Linear(768, 527)                         # whole submodule replaced
+    s3 = m._signature()
+    assert s3 != s2
+    with torch.no_grad():
+        m.head_audioset.bias.add_(1.0)                            # in-place edit inside the new submodule
+    s4 = m._signature()
+    assert s4 != s3 and m._signature() == s4
+    m.bn0.running_mean = torch.ones(224)                          # a buffer replaced
+    assert m._signature() != s4
+    # the cache holds no tensors: a replaced parameter is not kept alive by it
+    import weakref
+    old = m.stages[0][0].gamma
+    ref = weakref.ref(old)
+    m.stages[0][0].gamma = nn.Parameter(torch.ones(96))
+    del old
+    m._signature()
+    import gc
+    gc.collect()
+    assert ref() is None

@@ -153,3 +153,32 @@ def test_hdf5_shard_reader_with_a_stand_in_h5py(tmp_path, monkeypatch):
     assert [b["waveform"].shape[0] for b in batches] == [2, 2, 1]
     np.testing.assert_array_equal(batches[0]["waveform"], (store["waveform"][:2] / 32767.0).astype(np.float32))
     assert batches[2]["target"].dtype == np.float32 and batches[2]["audio_name"][0] == "Y0004.wav"
+
+
+def test_ahead_reader_thread_stops_when_the_consumer_leaves_early():
+    """the background reader of evaluate.forward must not block forever in q.put once its consumer is gone."""
+    import threading
+    import time
+    from audioset_convnext_inf_amd.pytorch import evaluate as ev
+    produced = []
+
+    def gen():
+        for i in range(1000):
+            produced.append(i)
+            yield i
+
+    before = threading.active_count()
+    it = ev._ahead(gen(), lambda x: x * 2)
+    assert next(it) == (0, 0) and next(it) == (1, 2)
+    it.close()                                   # consumer leaves (as an exception in the loop body would)
+    deadline = time.time() + 5
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() <= before
+    assert len(produced) < 10                    # the reader did not run on
+    # and an exception in the generator still reaches the consumer
+    def bad():
+        yield 1
+        raise ValueError("boom")
+    with pytest.raises(ValueError, match="boom"):
+        list(ev._ahead(bad(), lambda x: x))
