@@ -194,6 +194,7 @@ struct acx_ctx {
     // identity affine for acx_logmel_bn0(apply_bn0 = 0) (tests): per context, i.e. per device
     float* d_bn_one = nullptr;
     float* d_bn_zero = nullptr;
+    void* d_dw_sink = nullptr;     // kDwSinkBytes: where the column-streaming depthwise kernel stores rows that are not image rows
     acx::Profile prof;
 };
 
@@ -231,6 +232,12 @@ int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* 
 int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, void* out, hipStream_t s, bool act_bf16 = false);
 int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, float* stats, int B, int H,
                   int W, hipStream_t s, bool act_bf16 = false);
+// column-streaming form (dwconv_col.hip): same bits as the kernels of dwconv.hip; `sink` (kDwSinkBytes, device) takes the
+// stores of rows that are not part of the image; target_waves = waves the launch should spread over (one per SIMD)
+constexpr int kDwColMinRows = 16;            // output rows per wave segment below which the launch uses fewer waves
+constexpr size_t kDwSinkBytes = 64 * 1024;
+int launch_dwconv_col(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H, int W,
+                      bool act_bf16, int target_waves, hipStream_t s);
 // element-wise fp32 <-> bf16 (the per-layer entry points of the C ABI keep fp32 tensors in every mode)
 int launch_convert_f32_to_bf16(const float* in, void* out, long long n, hipStream_t s);
 int launch_convert_bf16_to_f32(const void* in, float* out, long long n, hipStream_t s);

@@ -176,6 +176,7 @@ static void free_device(acx_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
     for (int s = 0; s < 4; ++s) c->blocks[s].clear();
+    c->d_dw_sink = nullptr;
     c->finalized = false;
 }
 
@@ -259,6 +260,12 @@ static int finalize_impl(acx_ctx* c) {
         ACX_TRY(upload(c, sh, &c->d_bn_shift));
         ACX_TRY(upload(c, std::vector<float>(kMels, 1.f), &c->d_bn_one));
         ACX_TRY(upload(c, std::vector<float>(kMels, 0.f), &c->d_bn_zero));
+    }
+    {   // where the column-streaming depthwise kernel parks the stores of rows that are not image rows (dwconv_col.hip)
+        void* d = nullptr;
+        ACX_HIP(hipMalloc(&d, kDwSinkBytes));
+        c->allocs.push_back(d);
+        c->d_dw_sink = d;
     }
     // ---- stem -------------------------------------------------------------------------------
     ACX_TRY(upload(c, W(c, "downsample_layers.0.0.weight"), &c->d_stem_w));

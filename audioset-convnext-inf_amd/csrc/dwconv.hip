@@ -664,12 +664,35 @@ static int launch_dw_tile(const BlockW& w, int C, const void* x, void* y, int B,
     return ACX_OK;
 }
 
+// The column-streaming kernel (dwconv_col.hip) takes the launches whose waves get segments long enough to amortise their six
+// halo rows and their prologue: one wave per SIMD of the CUs this launch may count on (all of them, or its share while
+// acx_forward runs several sub-batches side by side).  Same bits either way (same accumulation order per output element);
+// ACX_DW_STREAM = 0 | 1 forces a form (tests).
+static bool use_col_kernel(const acx_ctx* c, int B, int H, int W, int* target_waves) {
+    if (!c || !c->d_dw_sink) return false;
+    const int force = tuning().dw_stream.load(std::memory_order_relaxed);
+    if (force == 0) return false;
+    int cus = 0;
+    if (cu_count_of_current_device(&cus) != ACX_OK) return false;
+    *target_waves = 4 * cus / inflight_ways();
+    if (force == 1) return true;
+    if (W != 56 && W != 28) return false;             // stages 2-3: cache-resident tensors, few rows per wave -- the tile kernel
+    const long long Vt = (long long)B * (H + 3) - 3;
+    return Vt / (*target_waves / 6 > 0 ? *target_waves / 6 : 1) >= 40;
+}
+
 int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, float* stats, int B, int H,
                   int W, hipStream_t s, bool act_bf16) {
     if (act_bf16 && stats) ACX_FAIL(ACX_ERR_STATE, "dwconv7: row statistics are computed from fp32 activations only");
     {
         ProfScope ps(c, ACX_K_DWCONV, s);
-        int rc;
+        int rc, target_waves = 0;
+        if (C == 96 * 56 / (W > 0 ? W : 1) && !(W == 7 && act_bf16) && use_col_kernel(c, B, H, W, &target_waves)) {
+            rc = launch_dwconv_col(x, y, w.dw, w.dwb, c->d_dw_sink, B, H, W, act_bf16, target_waves, s);
+            ACX_TRY(rc);
+            if (stats) ACX_TRY(launch_rowstats(c, reinterpret_cast<const float*>(y), stats, (int64_t)B * H * W, C, s));
+            return ACX_OK;
+        }
         switch (W) {
             case 56: rc = act_bf16 ? launch_dw_cfg<28, 8, true>(w, C, x, y, B, H, W, s) : launch_dw_cfg<28, 8, false>(w, C, x, y, B, H, W, s); break;
             case 28: rc = act_bf16 ? launch_dw_cfg<28, 8, true>(w, C, x, y, B, H, W, s) : launch_dw_cfg<28, 8, false>(w, C, x, y, B, H, W, s); break;
