@@ -235,7 +235,9 @@ int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, fl
 // column-streaming form (dwconv_col.hip): same bits as the kernels of dwconv.hip; `sink` (kDwSinkBytes, device) takes the
 // stores of rows that are not part of the image; target_waves = waves the launch should spread over (one per SIMD)
 constexpr int kDwColMinRows = 16;            // output rows per wave segment below which the launch uses fewer waves
-constexpr size_t kDwSinkBytes = 64 * 1024;
+constexpr int kDwSinkWindows = 128;                   // waves get sink windows of their own, modulo this
+constexpr size_t kDwSinkWindowBytes = 64 * 1024;      // >= a row's lane offsets + 6 pixel strides
+constexpr size_t kDwSinkBytes = kDwSinkWindows * kDwSinkWindowBytes;
 int launch_dwconv_col(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H, int W,
                       bool act_bf16, int target_waves, hipStream_t s);
 // element-wise fp32 <-> bf16 (the per-layer entry points of the C ABI keep fp32 tensors in every mode)

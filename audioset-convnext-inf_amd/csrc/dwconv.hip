@@ -676,9 +676,9 @@ static bool use_col_kernel(const acx_ctx* c, int B, int H, int W, int* target_wa
     if (cu_count_of_current_device(&cus) != ACX_OK) return false;
     *target_waves = 4 * cus / inflight_ways();
     if (force == 1) return true;
-    if (W != 56 && W != 28) return false;             // stages 2-3: cache-resident tensors, few rows per wave -- the tile kernel
+    if (W == 7) return false;                         // stage 3: 13 rows per wave at B = 64 -- the tile kernel
     const long long Vt = (long long)B * (H + 3) - 3;
-    return Vt / (*target_waves / 6 > 0 ? *target_waves / 6 : 1) >= 40;
+    return Vt / (*target_waves / 6 > 0 ? *target_waves / 6 : 1) >= (W == 14 ? 20 : 40);
 }
 
 int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, float* stats, int B, int H,

@@ -72,7 +72,17 @@ struct DwColCfg {
 #ifndef ACX_DWC_ABLATE
 #define ACX_DWC_ABLATE 0
 #endif
-#define ACX_DWC_PKFMA(d_, a_, b_, c_) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d_) : "v"(a_), "v"(b_), "v"(c_))
+// Accumulators are tied in/out operands ("+v") in BOTH forms: with a fresh output ("=v") inside the conditional kernel-row
+// blocks every accumulator becomes a phi of two values and hipcc shuffles them through AGPRs (851 v_accvgpr per loop body).
+// lab builds only: -DACX_DWC_STAMPS -> s_memtime at six points of every wave, written to acx_dwc_stamps[item][8]
+#ifdef ACX_DWC_STAMPS
+__device__ unsigned long long acx_dwc_stamps[4096 * 8];
+#define ACX_DWC_STAMP(k_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0 && item < 4096) acx_dwc_stamps[item * 8 + (k_)] = t_; }
+#else
+#define ACX_DWC_STAMP(k_)
+#endif
+#define ACX_DWC_PKFMA(acc_, a_, b_) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc_) : "v"(a_), "v"(b_))
+#define ACX_DWC_PKFMA_INIT(acc_, a_, b_, c_) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "+v"(acc_) : "v"(a_), "v"(b_), "v"(c_))
 
 // one 1-KB piece: lanes of `mask` fetch 16 bytes each from base + voff into lds + 16 lane
 template <unsigned long long MASK>
@@ -115,10 +125,17 @@ __device__ __forceinline__ void dwc_issue_pieces(const char* src, const unsigned
     }
 }
 
-// One input row: phase I of the rotation (static), ring slot I.
+// One input row: phase I of the rotation (static), ring slot I, kernel rows KLO .. KHI (static).
 //   rd      LDS address of this lane's first input column in ring slot 0
 //   real    the row is inside an image (wave-uniform): otherwise it contributes nothing
-template <int W, bool BF, int I>
+// A segment's first six input rows only meet the kernel rows whose output row lies inside the segment (KHI = 0 .. 5), its
+// last six likewise (KLO = 1 .. 6): the halo rows of a segment cost their loads, not their FMAs -- and the kernel-row range is
+// a template argument, the FMA stream stays straight-line code (a run-time test per kernel row made hipcc route weights and
+// accumulators through AGPRs: 730 v_accvgpr + 500 v_mov per loop body).
+// Order: input column by input column, left to right; a column meets every kernel row before the next one is touched (each
+// column is first needed 7+ FMAs after the one before it: the wave waits for the first LDS read only; an accumulator returns
+// after >= 7 other FMAs).  For one output element that is kernel column 0 .. 6 -- the order of dwconv.hip.
+template <int W, bool BF, int I, int KLO, int KHI>
 __device__ __forceinline__ void dwc_row(DwColState<W, BF>& st, const char* rd, bool real) {
     using Cfg = DwColCfg<W, BF>;
     constexpr int slot0 = (I + 6) % 7;            // the output row that starts here (kernel row 0)
@@ -136,22 +153,24 @@ __device__ __forceinline__ void dwc_row(DwColState<W, BF>& st, const char* rd, b
                 in[j] = *reinterpret_cast<const dwc_f32x2*>(rowp + s * Cfg::kSlotB);
             }
         }
-        // kx outer: an accumulator returns after >= 7 other FMAs, and input column j is first needed in round max(0, j - 6)
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx)
+        for (int j = 0; j < 13; ++j) {
+            if (W == 7 && (j < 3 || j > 9)) continue;
 #pragma unroll
-            for (int ky = 0; ky < 7; ++ky)
+            for (int ky = KLO; ky <= KHI; ++ky) {
+                const int a = (I - ky + 6 + 7) % 7;
 #pragma unroll
-                for (int p = 0; p < 7; ++p) {
-                    if (W == 7 && (p + kx < 3 || p + kx > 9)) continue;
+                for (int kx = (j > 6 ? j - 6 : 0); kx <= (j > 6 ? 6 : j); ++kx) {
+                    const int p = j - kx;
                     if (ACX_DWC_ABLATE == 1 && kx > 0) continue;
-                    const int a = (I - ky + 6 + 7) % 7;
                     // the first tap of a fresh output row adds to the bias; W = 7: its first in-image tap is kx = 3 - p
                     const bool first = ky == 0 && (W == 7 ? (kx == (p < 3 ? 3 - p : 0)) : kx == 0);
-                    if (first) { ACX_DWC_PKFMA(st.acc[a][p], in[p + kx], st.wt[ky * 7 + kx], st.bias); }
-                    else { ACX_DWC_PKFMA(st.acc[a][p], in[p + kx], st.wt[ky * 7 + kx], st.acc[a][p]); }
+                    if (first) { ACX_DWC_PKFMA_INIT(st.acc[a][p], in[j], st.wt[ky * 7 + kx], st.bias); }
+                    else { ACX_DWC_PKFMA(st.acc[a][p], in[j], st.wt[ky * 7 + kx]); }
                 }
-    } else {
+            }
+        }
+    } else if (KLO == 0) {
 #pragma unroll
         for (int p = 0; p < 7; ++p) st.acc[slot0][p] = st.bias;
     }
@@ -161,14 +180,16 @@ template <int W, bool BF>
 __global__ __launch_bounds__(256, 1) void dwconv7_col_kernel(const void* __restrict__ x_, void* __restrict__ y_,
                                                              const float* __restrict__ wt /*[49][C]*/,
                                                              const float* __restrict__ bias, void* __restrict__ sink_,
-                                                             int B, int H, int n_seg, int n_items) {
+                                                             int B, int H, int k7 /* output rows per segment / 7 */, int n_items,
+                                                             unsigned magic /* floor(2^32 / (H + 3)) + 1 */) {
     using Cfg = DwColCfg<W, BF>;
-    constexpr int C = Cfg::kC, kEsz = Cfg::kEsz;
+    constexpr int C = Cfg::kC, kEsz = Cfg::kEsz, D = Cfg::kD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int item = (int)blockIdx.x * 4 + wave;
     if (item >= n_items) return;                      // (no barrier in this kernel: a wave may leave alone)
+    ACX_DWC_STAMP(0)
     const int unit = item % Cfg::kUnits, seg = item / Cfg::kUnits;
     const int half = unit % Cfg::kHalves, sg = unit / Cfg::kHalves;
     const int cbase = sg * Cfg::kSlices * 32;
@@ -179,17 +200,10 @@ __global__ __launch_bounds__(256, 1) void dwconv7_col_kernel(const void* __restr
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
 
     // ---- compute roles: 16 lanes x float2 = one pixel's 32-channel slice ----
-    const int g = lane >> 4, l16 = lane & 15;
-    const int strip = g % Cfg::kStrips, sl_i = g / Cfg::kStrips;
+    const int g4 = lane >> 4, l16 = lane & 15;
+    const int strip = g4 % Cfg::kStrips, sl_i = g4 / Cfg::kStrips;
     const int ch = cbase + sl_i * 32 + 2 * l16;
     DwColState<W, BF> st;
-#pragma unroll
-    for (int t = 0; t < 49; ++t) st.wt[t] = *reinterpret_cast<const dwc_f32x2*>(wt + t * C + ch);
-    st.bias = *reinterpret_cast<const dwc_f32x2*>(bias + ch);
-#pragma unroll
-    for (int a = 0; a < 7; ++a)
-#pragma unroll
-        for (int p = 0; p < 7; ++p) st.acc[a][p] = st.bias;
     const char* const rd = ring + sl_i * Cfg::kSlots * Cfg::kSlotB + strip * 7 * Cfg::kSlotB + l16 * (BF ? 4 : 8);
     const unsigned yoff = (unsigned)(((half * Cfg::kPx + strip * 7) * C + ch) * kEsz);
 
@@ -203,87 +217,138 @@ __global__ __launch_bounds__(256, 1) void dwconv7_col_kernel(const void* __restr
         voff[p] = (unsigned)((col * C + cbase + sl * 32) * kEsz + (lane % Cfg::kLanesPerSlot) * 16);
     }
 
-    // ---- the segment: output rows [vb, ve) of the stacked image, input rows [vb - 3, ve + 3) ----
+    // ---- the segment: 7 k7 output rows [vb, ve) of the stacked image (stacked row v = clip * (H + 3) + row; row >= H: one of
+    // the three zero rows between clips; the last segment may reach past the last clip), input rows [vb - 3, ve + 3).  Step u
+    // multiplies input row vb - 3 + u and completes output row vb - 6 + u; the 7 k7 + 6 steps run as groups of seven.
     const int Hp = H + 3;
-    const long long Vt = (long long)B * Hp - 3;
-    const int vb = (int)(Vt * seg / n_seg), ve = (int)(Vt * (seg + 1) / n_seg);
-    const int steps = ve - vb + 6;
-    if (ve <= vb) return;
+    const int n_out = 7 * k7;
+    const int vb = seg * n_out;
     const char* const x0 = reinterpret_cast<const char*>(x_);
-    // prefetch cursor: stacked row vb - 3 (may be -3 .. -1: rows above the first clip)
-    int r_pf;                                                       // row inside its clip (>= H: one of the 3 zero rows)
-    const char* pf_ptr;                                             // next in-image row at or after the cursor
+    const char* pf_ptr;                                             // next in-image row at or after the prefetch cursor
     {
         const int v0 = vb - 3 + Hp;                                 // >= 0
-        const int n1 = v0 / Hp;
-        r_pf = v0 - n1 * Hp;
-        const long long rows_before = (long long)(n1 - 1) * H + (r_pf < H ? r_pf : H);
-        pf_ptr = x0 + rows_before * Cfg::kGRowB;
+        const int n1 = v0 / Hp, r0 = v0 - n1 * Hp;
+        pf_ptr = x0 + ((long long)(n1 - 1) * H + (r0 < H ? r0 : H)) * Cfg::kGRowB;
     }
     char* out_ptr;                                                  // next in-image output row at or after vb
     {
         const int n = vb / Hp, r = vb - n * Hp;
         out_ptr = reinterpret_cast<char*>(y_) + ((long long)n * H + (r < H ? r : H)) * Cfg::kGRowB;
     }
-    char* const sink = reinterpret_cast<char*>(sink_);
-    unsigned hist = 0;                                              // bit i: was the row prefetched i + 1 rows ago in-image?
-    int u_pf = 0;                                                   // rows prefetched so far
+    // Stores of rows that are not this wave's (the six steps above its segment, the rows between clips) go to a sink.  Every wave
+    // gets a window of its own there (modulo kDwSinkWindows): a thousand waves storing to the same lines serialise in one L2 channel.
+    char* const sink = reinterpret_cast<char*>(sink_) + (size_t)(item % kDwSinkWindows) * kDwSinkWindowBytes;
 
-    // zero the ring (the out-of-image column slots stay zero for good), then the first kD rows
-    for (int i = lane; i < Cfg::kWaveLds / 16; i += 64) reinterpret_cast<dwc_f32x4*>(ring)[i] = dwc_f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#define ACX_DWC_PREFETCH(slot_)                                                                                 \
+    // Row flags of a group of seven steps, computed by the lanes and read back as wave-uniform bit masks (one v_cmp each):
+    // lane l looks at step u = 7 g - 3 + l; bit l of rmask: that input row is inside an image; bit l of omask: it is an
+    // output row this wave stores.
+    unsigned rmask = 0, omask = 0;
+#define ACX_DWC_FLAGS(g_)                                                                                       \
     {                                                                                                           \
-        const bool real_ = r_pf < H && u_pf < steps;                                                            \
-        hist = (hist << 1) | (real_ ? 1u : 0u);                                                                 \
-        const char* src_ = real_ ? pf_ptr : x0;                                                                 \
+        const int u_ = 7 * (g_) - 3 + lane;                                                                     \
+        const int v_ = vb - 3 + u_;                                                                             \
+        const unsigned vv_ = (unsigned)(v_ + 9 * Hp);                 /* >= 0: v_ >= -9, Hp >= 4 */             \
+        const unsigned n_ = __umulhi(vv_, magic);                                                               \
+        const unsigned r_ = vv_ - n_ * (unsigned)Hp;                                                            \
+        const bool real_ = v_ >= 0 && r_ < (unsigned)H && n_ < (unsigned)(B + 9) && u_ >= 0 && u_ < n_out + 6;  \
+        rmask = (unsigned)__ballot(real_);                                                                      \
+        omask = (unsigned)__ballot(real_ && u_ >= 3 && u_ < n_out + 3);                                         \
+    }
+
+    // The out-of-image column slots of the ring are zeroed once and never written again (the three slots left and right of every
+    // slice's pixels; W = 56: only the outer side of each half), then the first kD rows are requested -- BEFORE the weights: the
+    // prologue is one memory latency, not two (weights first cost 7 k cycles per wave before the first row was even requested).
+    if constexpr (Cfg::kHalo > 0) {
+        constexpr int kChunks = Cfg::kSlotB / 16;                              // 16-byte chunks per slot
+        constexpr int kZ = 7 * Cfg::kSlices * 2 * Cfg::kHalo * kChunks;      // chunks to zero
+        for (int i = lane; i < kZ; i += 64) {
+            const int c = i % kChunks, s6 = (i / kChunks) % (2 * Cfg::kHalo), rs = i / kChunks / (2 * Cfg::kHalo);
+            const int slot = s6 < Cfg::kHalo ? s6 : Cfg::kPx + s6;              // 0, 1, 2, kPx + 3, kPx + 4, kPx + 5
+            *reinterpret_cast<dwc_f32x4*>(ring + (rs / Cfg::kSlices) * Cfg::kRowB + ((rs % Cfg::kSlices) * Cfg::kSlots + slot) * Cfg::kSlotB + 16 * c) =
+                dwc_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // row u of the current group's window is bit u - 7 g + 3
+    // Every step requests a row (the counted wait relies on it); a step whose row is not part of an image re-requests the
+    // wave's latest real row (from the cache) -- never one address for all waves: that serialises in one L2 channel.
+    const char* safe_src = pf_ptr;
+#define ACX_DWC_PREFETCH(bit_, slot_)                                                                           \
+    {                                                                                                           \
+        const bool real_ = (rmask >> (bit_)) & 1u;                                                              \
+        const char* src_ = real_ ? pf_ptr : safe_src;                                                           \
+        safe_src = src_;                                                                                        \
         pf_ptr += real_ ? Cfg::kGRowB : 0;                                                                      \
-        r_pf = r_pf + 1 == Hp ? 0 : r_pf + 1;                                                                   \
-        ++u_pf;                                                                                                 \
         dwc_issue_pieces<W, BF, 0>(src_, voff, ring_lds + (unsigned)((slot_) * Cfg::kRowB), first_real);        \
     }
+    ACX_DWC_FLAGS(0)
 #pragma unroll
-    for (int i = 0; i < Cfg::kD; ++i) ACX_DWC_PREFETCH(i)
+    for (int i = 0; i < D; ++i) ACX_DWC_PREFETCH(i + 3, i)
+    ACX_DWC_STAMP(1)
+#pragma unroll
+    for (int t = 0; t < 49; ++t) st.wt[t] = *reinterpret_cast<const dwc_f32x2*>(wt + t * C + ch);
+    st.bias = *reinterpret_cast<const dwc_f32x2*>(bias + ch);
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int p = 0; p < 7; ++p) st.acc[a][p] = st.bias;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // once: the steady state below counts whole steps
+    ACX_DWC_STAMP(2)
 
-    int j = 0;                                           // step = input row vb - 3 + j, output row vb - 6 + j
-#define ACX_DWC_STEP(I_)                                                                                        \
+#define ACX_DWC_STEP(I_, KLO_, KHI_)                                                                            \
     {                                                                                                           \
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ACX_DWC_ABLATE >= 2 ? 0 : Cfg::kWait) : "memory");           \
-        ACX_DWC_PREFETCH(((I_) + Cfg::kD) % 7)                                                                  \
-        const bool in_real_ = (hist >> Cfg::kD) & 1u;                                                           \
-        dwc_row<W, BF, I_>(st, rd, in_real_);                                                                   \
-        const bool out_ok_ = ((hist >> (Cfg::kD + 3)) & 1u) && j >= 6;                                          \
+        ACX_DWC_PREFETCH((I_) + D + 3, ((I_) + D) % 7)                                                          \
+        dwc_row<W, BF, I_, KLO_, KHI_>(st, rd, (rmask >> ((I_) + 3)) & 1u);                                     \
+        const bool out_ok_ = (omask >> (I_)) & 1u;                                                              \
         char* dst_ = (out_ok_ ? out_ptr : sink) + yoff;                                                         \
         out_ptr += out_ok_ ? Cfg::kGRowB : 0;                                                                   \
         _Pragma("unroll") for (int p = 0; p < (ACX_DWC_ABLATE == 3 ? 0 : 7); ++p) {                             \
             if constexpr (BF) *reinterpret_cast<unsigned*>(dst_ + p * C * kEsz) = acx_pack_bf16x2(st.acc[I_][p].x, st.acc[I_][p].y); \
             else *reinterpret_cast<dwc_f32x2*>(dst_ + p * C * kEsz) = st.acc[I_][p];                            \
         }                                                                                                       \
-        if (++j == steps) break;                                                                                \
     }
-    for (;;) {
-        ACX_DWC_STEP(0) ACX_DWC_STEP(1) ACX_DWC_STEP(2) ACX_DWC_STEP(3) ACX_DWC_STEP(4) ACX_DWC_STEP(5) ACX_DWC_STEP(6)
+    // group 0: the first six input rows meet kernel rows 0 .. step only (the output rows above the segment are not this wave's)
+    ACX_DWC_STEP(0, 0, 0) ACX_DWC_STEP(1, 0, 1) ACX_DWC_STEP(2, 0, 2) ACX_DWC_STEP(3, 0, 3) ACX_DWC_STEP(4, 0, 4) ACX_DWC_STEP(5, 0, 5)
+    ACX_DWC_STEP(6, 0, 6)
+    ACX_DWC_STAMP(3)
+    for (int g = 1; g < k7; ++g) {
+        ACX_DWC_FLAGS(g)
+        ACX_DWC_STEP(0, 0, 6) ACX_DWC_STEP(1, 0, 6) ACX_DWC_STEP(2, 0, 6) ACX_DWC_STEP(3, 0, 6) ACX_DWC_STEP(4, 0, 6) ACX_DWC_STEP(5, 0, 6) ACX_DWC_STEP(6, 0, 6)
     }
+    // the last six input rows: kernel rows step + 1 .. 6 (the output rows below the segment belong to the next wave)
+    ACX_DWC_STAMP(4)
+    ACX_DWC_FLAGS(k7)
+    ACX_DWC_STEP(0, 1, 6) ACX_DWC_STEP(1, 2, 6) ACX_DWC_STEP(2, 3, 6) ACX_DWC_STEP(3, 4, 6) ACX_DWC_STEP(4, 5, 6) ACX_DWC_STEP(5, 6, 6)
+    ACX_DWC_STAMP(5)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ACX_DWC_STAMP(6)
 #undef ACX_DWC_STEP
 #undef ACX_DWC_PREFETCH
+#undef ACX_DWC_FLAGS
 }
 
-// target_waves: how many waves the launch should consist of (one per SIMD of the CUs it may use)
+// target_waves: how many waves the launch should consist of (one per SIMD of the CUs it may use).  Every wave takes a
+// segment of 7 k output rows of the stacked batch (the rotation has seven phases: the first and the last six steps then sit at
+// fixed phases and are compiled with their reduced kernel-row ranges).
 template <int W, bool BF>
 static int launch_dw_col_cfg(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H,
                              int target_waves, hipStream_t s) {
     using Cfg = DwColCfg<W, BF>;
     const long long Vt = (long long)B * (H + 3) - 3;
-    if (Vt > 0x7fffffffll) ACX_FAIL(ACX_ERR_SHAPE, "dwconv7: batch too tall for one launch (%d clips of %d rows)", B, H);
-    long long n_seg = target_waves / Cfg::kUnits;
-    if (n_seg > Vt / kDwColMinRows) n_seg = Vt / kDwColMinRows;
-    if (n_seg < 1) n_seg = 1;
+    // exactness of v / (H + 3) by multiply-high needs (stacked rows + 9 (H + 3) + slack) * (H + 3) < 2^32
+    if ((Vt + 16ll * (H + 3) + 64) * (H + 3) >= 0xffffffffll)
+        ACX_FAIL(ACX_ERR_SHAPE, "dwconv7: batch too tall for one launch (%d clips of %d rows)", B, H);
+    long long segs = target_waves / Cfg::kUnits;
+    if (segs < 1) segs = 1;
+    long long k7 = (Vt + 7 * segs - 1) / (7 * segs);                   // ceil(rows per segment / 7)
+    if (k7 < (kDwColMinRows + 6) / 7) k7 = (kDwColMinRows + 6) / 7;
+    const long long n_seg = (Vt + 7 * k7 - 1) / (7 * k7);
     const int n_items = (int)(n_seg * Cfg::kUnits);
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &dwconv7_col_kernel<W, BF>, Cfg::kLdsBytes));
     dwconv7_col_kernel<W, BF><<<dim3((unsigned)((n_items + 3) / 4)), dim3(256), Cfg::kLdsBytes, s>>>(
-        x, y, wt, bias, sink, B, H, (int)n_seg, n_items);
+        x, y, wt, bias, sink, B, H, (int)k7, n_items, (unsigned)(0x100000000ull / (unsigned)(H + 3)) + 1u);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

@@ -87,10 +87,38 @@ int run_case(int B, int H, int W, bool bf, int iters, int target_waves, bool che
     return bad;
 }
 
+#ifdef ACX_DWC_STAMPS
+static void stamp_case(int B, int H, int W, int waves) {
+    const int C = 96 * 56 / W; const size_t n = (size_t)B * H * W * C;
+    void *x, *y, *sink; float *dw, *db;
+    CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&y, n * 4)); CK(hipMalloc(&sink, kDwSinkBytes)); CK(hipMalloc(&dw, 49 * C * 4)); CK(hipMalloc(&db, C * 4));
+    CK(hipMemset(x, 0, n * 4)); CK(hipMemset(dw, 0, 49 * C * 4)); CK(hipMemset(db, 0, C * 4));
+    std::vector<unsigned long long> st(4096 * 8, 0);
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(acx_dwc_stamps), st.data(), st.size() * 8));
+    for (int i = 0; i < 6; ++i) launch_dwconv_col(x, y, dw, db, sink, B, H, W, false, waves, nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(acx_dwc_stamps), st.size() * 8));
+    unsigned long long t0 = ~0ull, t6 = 0; int items = 0;
+    for (int i = 0; i < 4096; ++i) if (st[i * 8 + 6]) { ++items; if (st[i * 8] < t0) t0 = st[i * 8]; if (st[i * 8 + 6] > t6) t6 = st[i * 8 + 6]; }
+    double avg[7] = {0};
+    CK(hipMemset(x, 0, 64));
+    for (int i = 0; i < 4096; ++i) if (st[i * 8 + 6]) for (int k = 0; k < 7; ++k) avg[k] += (double)(st[i * 8 + k] - st[i * 8]) / items;
+    printf("W=%d B=%d: %d waves; mean stamp (k cycles from the wave's own start):", W, B, items);
+    const char* names[7] = {"start", "prologue issued", "first rows landed", "group 0 done", "main loop done", "epilogue done", "stores drained"};
+    for (int k = 0; k < 7; ++k) printf("  %s %.1f", names[k], avg[k] / 1e3);
+    printf("\n");
+    hipFree(x); hipFree(y); hipFree(sink); hipFree(dw); hipFree(db);
+}
+#endif
+
 int main(int argc, char** argv) {
     const int waves = argc > 1 ? atoi(argv[1]) : 1024;
     int bad = 0;
     const int Hs[4] = {252, 126, 63, 31}, Ws[4] = {56, 28, 14, 7};
+#ifdef ACX_DWC_STAMPS
+    for (int s = 0; s < 4; ++s) stamp_case(64, Hs[s], Ws[s], waves);
+    return 0;
+#endif
     if (argc > 2) {          // timing only: B=64 at `waves`, B=32 at waves and waves/2
         for (int s = 0; s < 4; ++s) run_case(64, Hs[s], Ws[s], false, 20, waves, false);
         for (int s = 0; s < 4; ++s) run_case(32, Hs[s], Ws[s], false, 20, waves, false);
