@@ -1,10 +1,11 @@
 // K4s/K5s -- the dense contractions with fp32 operands carried as TWO fp16 halves (ACX_PREC_F32_SPLIT).
 //
 // v_mfma_f32_32x32x2_f32 runs at 1/16 of the fp16 matrix rate on gfx950 (157 vs 2500 TFLOP/s).  An fp32 value v
-// is v = hi + lo + e with hi = fp16(v), lo = fp16(v - hi), |e| <= 2^-24 |v| (two round-to-nearest 11-bit pieces
-// cover 24 significant bits; gfx950 MFMA honours fp16 subnormals -- tools/mfma_denorm_probe.hip -- and a
+// is v = hi + lo + e with hi = fp16(v), lo = fp16(v - hi), |e| <= 2^-23 |v| in the worst case (two round-to-nearest 11-bit
+// pieces: exact for ~40 % of random fp32 mantissas, one bit short of fp32's 24 in the worst case -- measured on 2^20 values in
+// tests/test_split_arithmetic_cpu.py; gfx950 MFMA honours fp16 subnormals -- tools/mfma_denorm_probe.hip -- and a
 // power-of-two pre-scale keeps the pieces far from the bottom of the fp16 range).  A product of two such values is
-//   a b = ah bh + ah bl + al bh + (al bl ~ 2^-24 a b, dropped),
+//   a b = ah bh + ah bl + al bh + (al bl <= 2^-22 a b, dropped),
 // every partial product of two fp16 numbers is exact in fp32 and the matrix core accumulates them in fp32, so three
 // fp16 MFMAs reproduce an fp32 FMA chain to within the rounding of the fp32 accumulation itself -- at 16/3 of the
 // f32-MFMA rate.  tests/test_gpu_parity.py runs its whole suite against this mode at the fp32 tolerances.

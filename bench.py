@@ -11,8 +11,9 @@ disagrees with a launcher's WORLD_SIZE is an error, not a warning.
 
 One "step" = one pass of the hot path (waveform -> logits+probs) over one batch of synthetic 10 s /
 32 kHz clips that is already resident in HBM.  N = 1 runs BASELINE config 2 (ConvNeXt-Tiny, bs=64,
-fp32).  The default arithmetic is "fp32_split": every fp32 GEMM operand is carried as fp16 hi + fp16 lo (24
-significant bits), each product is three fp16 MFMAs accumulated in fp32 -- fp32-grade results (the whole GPU
+fp32).  The default arithmetic is "fp32_split": every fp32 GEMM operand is carried as fp16 hi + fp16 lo (representation error
+<= 2^-23 relative, i.e. 23 of fp32's 24 significant bits in the worst case; the lo*lo term of a product, <= 2^-22, is dropped), each product
+is three fp16 MFMAs accumulated in fp32 -- fp32-grade results (the whole GPU
 parity suite runs on it at the fp32 tolerances, include/acx.h) at 16/3 of the f32-MFMA rate; the same run also
 times the native f32-MFMA path (`--precision fp32`) and reports it as `native_f32_mfma`. N > 1 keeps 64 clips per GPU (weak scaling: clips are independent, every rank holds a full
 weight replica) and includes the one collective of the path -- the RCCL all-gather of the logits --
@@ -22,6 +23,10 @@ The library runs a batch of 16 clips or more as two sub-batches side by side on 
 says how many; ACX_SPLIT_STREAMS=0 turns it off): `value` times the forward as the library runs it.
 
 Extra objects on that line:
+  bf16a_shard  -- BASELINE configs[2]'s per-rank workload (64 x 10 s, set_precision("bf16a")) timed in the same process:
+                  value, ms_per_step, its own kernels / roofline / roofline_dwconv (traffic from profiles/*_bf16a_traffic.json).
+  frame_bs256  -- BASELINE configs[3]: forward_frame_embeddings at bs = 256: clips/s and the depthwise conv's GB/s.
+                  (Both only at N = 1 with the default arithmetic; --no-extra-configs skips them.)
   roofline     -- the dominant KERNEL (by device time; the event classes pw1 + pw2 are one kernel,
                   gemm_split_kernel, and are merged): algorithmic FLOPs per launch / average launch duration (HIP
                   events on the launch stream, taken in a separate profiled pass of the same workload so that
@@ -135,12 +140,13 @@ def algorithmic_work(B, L, precision="fp32"):
     return work
 
 
-def measured_traffic():
-    """HBM bytes per launch per kernel class from the newest committed rocprofv3 PMC summary under profiles/
-    (tools/pmc_table.py: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes).  PMC counters cannot be read from
+def measured_traffic(precision="fp32_split"):
+    """HBM bytes per launch per kernel class from the newest committed rocprofv3 PMC summary of THIS arithmetic under
+    profiles/ (tools/pmc_table.py: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes).  PMC counters cannot be read from
     inside this process, so `traffic` is the profiled figure of the same workload, not a live measurement."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
+    tag = {"fp32_split": "split", "bf16a": "bf16a", "bf16": "bf16", "fp32": "fp32"}[precision]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % tag)))
     if not files:
         return {}, None
     try:
@@ -150,11 +156,27 @@ def measured_traffic():
         return {}, None
 
 
+def _cpu_worker(args):
+    """One process of the whole-host aggregate: `threads` torch threads, `reps` forwards of `b` clips."""
+    threads, b, reps = args
+    import torch as _t
+    from oracle import ref_cpu
+    _t.set_num_threads(threads)
+    sd = synth.synth_state_dict(0)
+    wav = synth.synth_waveforms(b, CLIP_SAMPLES, seed=1234)
+    ref_cpu.forward(sd, wav[:1])
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ref_cpu.forward(sd, wav)
+    return b * reps, time.perf_counter() - t0
+
+
 def cpu_baseline():
     """Time the oracle on the host cores (B in {1, 8, 64}, best clips/s reported).  torch-CPU scales badly
     past a few dozen threads on this graph (and the box may expose more logical CPUs than it grants), so first probe
     a few thread counts on two clips, then time B = 1 (3 reps), 8 (2 reps) and 64 (1 rep) with the best one:
-    about 20-30 s of CPU work in all."""
+    about 20-30 s of CPU work in all.  `value` is ONE process; `whole_host` adds, once, the aggregate of N such processes
+    side by side (N x threads = the logical CPUs available, at most 16 processes), so that the whole-host figure is on record."""
     from oracle import ref_cpu
     sd = synth.synth_state_dict(0)
     try:
@@ -180,12 +202,25 @@ def cpu_baseline():
             best = min(best, time.perf_counter() - t0)
         per_batch[b] = b / best
     value = max(per_batch.values())
-    return {"value": value, "unit": "clips/s", "cores": threads, "kind": "port",
-            "clips_per_s_by_batch": {str(k): round(v, 3) for k, v in per_batch.items()},
-            "sample": "oracle/ref_cpu.forward (torch-CPU fp32, the reference's op sequence) on 10 s @ 32 kHz clips at "
+    whole = None
+    nproc = max(1, min(16, avail // threads))
+    if nproc > 1:
+        try:
+            import multiprocessing as mp
+            with mp.get_context("spawn").Pool(nproc) as pool:
+                t0 = time.perf_counter()
+                res = pool.map(_cpu_worker, [(threads, 8, 1)] * nproc)
+                wall = time.perf_counter() - t0
+            whole = {"processes": nproc, "threads_each": threads, "clips_per_s": sum(r[0] for r in res) / max(r[1] for r in res),
+                     "clips_per_s_incl_process_start": sum(r[0] for r in res) / wall, "sample": "%d processes x one forward of 8 clips each" % nproc}
+        except Exception as e:                              # the baseline must never take the bench line down
+            whole = {"error": repr(e)[:200]}
+    return {"value": value, "unit": "clips/s", "cores": threads, "kind": "port", "processes": 1,
+            "clips_per_s_by_batch": {str(k): round(v, 3) for k, v in per_batch.items()}, "whole_host": whole,
+            "sample": "ONE process of oracle/ref_cpu.forward (torch-CPU fp32, the reference's op sequence) on 10 s @ 32 kHz clips at "
                       "batch 1 (best of 3), 8 (best of 2) and 64 (one pass); value = the best of the three; "
-                      "thread-count probe (clips/s on 2 clips): %s; %d logical CPUs available"
-                      % ({k: round(v, 2) for k, v in probe.items()}, avail)}
+                      "thread-count probe (clips/s on 2 clips): %s; %d logical CPUs available; whole_host = N such "
+                      "processes side by side, measured once" % ({k: round(v, 2) for k, v in probe.items()}, avail)}
 
 
 def _free_port():
@@ -252,6 +287,107 @@ def self_launch(n, argv):
     return 0
 
 
+def profile_rooflines(model, dev, fn, B, precision, n_prof, L=CLIP_SAMPLES):
+    """A separate profiled pass of `fn` (HIP-event pairs around every launch, un-split on one stream): per-class device time,
+    the roofline of the dominant matrix kernel, of the other matrix kernels, and of the depthwise conv."""
+    bf16 = precision in ("bf16", "bf16a")
+    split = precision == "fp32_split"
+    out = {}
+    ctx = model.native_context(dev)
+    ctx.profile(True)
+    for _ in range(n_prof):
+        fn()
+    torch.cuda.synchronize(dev)
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    work = algorithmic_work(B, L, precision)
+    kernels = {}
+    for k, (ms, n) in prof.items():
+        if n == 0:
+            continue
+        flops, nbytes = work[k][0] * n_prof, work[k][1] * n_prof
+        kernels[k] = {"launches_per_step": n // n_prof, "ms_per_step": ms / n_prof,
+                      "tflops": flops / (ms * 1e-3) / 1e12 if flops else None,
+                      "algorithmic_GBs": nbytes / (ms * 1e-3) / 1e9}
+    out["kernels"] = kernels
+    # the matrix kernels by NAME: the event classes pw1 and pw2 are launches of one kernel
+    gemm_name = {"fp32": "gemm_f32_kernel", "bf16": "gemm_bf16_kernel", "bf16a": "gemm_bf16_kernel", "fp32_split": "gemm_split16_kernel"}[precision]
+    fused_name = {"fp32": "mlp_fused_kernel", "bf16": "mlp_fused_bf16_kernel", "bf16a": "mlp_fused_bf16_kernel", "fp32_split": "mlp_fused_split_kernel"}[precision]
+    groups = {gemm_name + " (pwconv1+GELU and pwconv2+residual launches, two-GEMM stages)": ("pw1", "pw2"),
+              fused_name + " (LN+pwconv1+GELU+pwconv2+residual in one launch)": ("mlp_fused",),
+              ("mlp_fused_wide_bf16_kernel (LN+pwconv1+GELU+pwconv2+residual in one launch, stages 0-2)" if bf16 else
+               "mlp_fused_wide_kernel (LN+pwconv1+GELU+pwconv2+residual in one launch, stages 1-2)"): ("mlp_wide",)}
+    merged = {}
+    for name, ks in groups.items():
+        ks = [k for k in ks if k in kernels]
+        if not ks:
+            continue
+        n = sum(kernels[k]["launches_per_step"] for k in ks)
+        merged[name] = {"ms": sum(kernels[k]["ms_per_step"] for k in ks), "launches": n,
+                        "flops": sum(work[k][0] for k in ks), "bytes": sum(work[k][1] for k in ks)}
+    # split mode executes 3 fp16 MFMA flops per algorithmic fp32 flop: the algorithmic peak of that arithmetic is the
+    # dense fp16 peak / 3
+    raw_peak = MFMA_BF16_PEAK_TF if (bf16 or split) else MFMA_F32_PEAK_TF
+    mfma_mult = 3.0 if split else 1.0
+    peak = raw_peak / mfma_mult
+    dom = max(merged, key=lambda k: merged[k]["ms"])
+    g = merged[dom]
+    per_launch_flops = g["flops"] / g["launches"]
+    avg_launch_s = g["ms"] * 1e-3 / g["launches"]
+    ach = per_launch_flops / avg_launch_s / 1e12
+    traffic, traffic_src = measured_traffic(precision)
+    tr = lambda k: (traffic.get(k, {}).get("hbm_traffic_bytes_per_launch") if (B == 64 and L == CLIP_SAMPLES) else None)
+    dom_classes = [k for k in groups[dom] if k in kernels]
+    tr_dom = [tr(k) for k in dom_classes]
+    tr_dom = (sum(t * kernels[k]["launches_per_step"] for t, k in zip(tr_dom, dom_classes)) / g["launches"]
+              if all(t is not None for t in tr_dom) else None)
+    out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                       "frac": ach / peak, "frac_executed": mfma_mult * ach / raw_peak,
+                       "frac_algorithmic_vs_fp16_peak" if (split or bf16) else "frac_algorithmic": ach / raw_peak,
+                       "peak_note": ("dense fp16 MFMA peak %.0f TFLOP/s / %d MFMAs per fp32 product" % (raw_peak, int(mfma_mult)))
+                                    if split else "dense MFMA peak of the operand type",
+                       "traffic": tr_dom, "traffic_source": traffic_src, "avg_launch_ms": avg_launch_s * 1e3,
+                       "launches_per_step": g["launches"], "ms_per_step": g["ms"],
+                       "algorithmic_flops_per_launch": per_launch_flops,
+                       "executed_mfma_flops_per_launch": mfma_mult * per_launch_flops,
+                       "algorithmic_bytes_per_launch": g["bytes"] / g["launches"]}
+    if split:
+        pk = 1024 * 1024 * SPLIT_SHADER_CLOCK_GHZ / 1e3 / 3.0     # SIMDs x flop/cycle/SIMD x GHz / 3 -> TFLOP/s algorithmic
+        out["roofline"].update({"shader_clock_GHz_in_kernel_pmc": SPLIT_SHADER_CLOCK_GHZ,
+                                "peak_at_that_clock": pk, "frac_at_that_clock": ach / pk})
+    if bf16:        # at bf16 rates a kernel may be bound by its HBM traffic, not the matrix pipe: report the binding one, keep both
+        gbs = g["bytes"] / g["launches"] / avg_launch_s / 1e9
+        out["roofline"].update({"mfma_tflops": ach, "mfma_frac": ach / peak, "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
+        if gbs / HBM_PEAK_GBS > ach / peak:
+            out["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+    out["roofline_other_matrix_kernels"] = {
+        k: {"achieved": v["flops"] / (v["ms"] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, "ms_per_step": v["ms"], "launches_per_step": v["launches"]}
+        for k, v in merged.items() if k != dom}
+    mf = sum(v["flops"] for v in merged.values()) / sum(v["ms"] * 1e-3 for v in merged.values()) / 1e12
+    out["roofline_all_pointwise"] = {"bound": "mfma", "achieved": mf, "peak": peak, "unit": "TFLOP/s", "frac": mf / peak}
+    dw = kernels["dwconv"]
+    out["roofline_dwconv"] = {"kernel": "dwconv7_col_kernel (stages 0-2) + dwconv7_tile_kernel (stage 3)", "bound": "hbm",
+                              "achieved": dw["algorithmic_GBs"],
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dw["algorithmic_GBs"] / HBM_PEAK_GBS,
+                              "frac_of_copy_rate": dw["algorithmic_GBs"] / HBM_COPY_GBS, "copy_rate": HBM_COPY_GBS,
+                              "traffic": tr("dwconv"), "traffic_source": traffic_src, "ms_per_step": dw["ms_per_step"],
+                              "launches_per_step": dw["launches_per_step"],
+                              "algorithmic_bytes_per_launch": work["dwconv"][1] / dw["launches_per_step"]}
+    return out
+
+
+def timed(fn, dev, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,6 +401,7 @@ def main():
                          "bf16 = the arithmetic of configs[2] (bf16 contractions, fp32 LayerNorm / residual / accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the bf16a_shard / frame_bs256 sub-objects")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU plumbing check of the multi-rank path (gloo, a stand-in model, no GPU): launch, rendezvous, "
                          "barriers, gather and the JSON line; the line is marked dry_run and measures nothing")
@@ -361,8 +498,8 @@ def main():
         "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("bf16 (contractions and stored activations of stages 0-2)" if args.precision == "bf16a" else "bf16") if bf16 else ("f32 (GEMM operands as fp16 hi+lo pairs = 24 significant bits, 3 fp16 MFMAs per "
-                                      "product, fp32 accumulate; all else fp32)" if split else "f32"),
+        "dtype": ("bf16 (contractions and stored activations of stages 0-2)" if args.precision == "bf16a" else "bf16") if bf16 else ("f32 (GEMM operands as fp16 hi+lo pairs: representation error <= 2^-23 relative, lo*lo <= 2^-22 dropped; "
+                                      "3 fp16 MFMAs per product, fp32 accumulate; all else fp32)" if split else "f32"),
         "data": "synthetic", "rccl_ranks": joined,
         "config": {"workload": "ConvNeXt-Tiny bs=%d per GPU, synthetic 10 s @ 32 kHz waveforms resident in HBM, "
                                "waveform -> %s, %s" % (B, args.mode, "bf16 contractions with fp32 LayerNorm (arithmetic of "
@@ -391,88 +528,7 @@ def main():
         return
 
     if rank == 0 and not args.no_profile:
-        ctx = model.native_context(dev)
-        ctx.profile(True)
-        n_prof = max(1, min(args.steps, 5))
-        for _ in range(n_prof):
-            fn()
-        torch.cuda.synchronize(dev)
-        prof = ctx.profile_read()
-        ctx.profile(False)
-        work = algorithmic_work(B, CLIP_SAMPLES, args.precision)
-        kernels = {}
-        for k, (ms, n) in prof.items():
-            if n == 0:
-                continue
-            flops, nbytes = work[k][0] * n_prof, work[k][1] * n_prof
-            kernels[k] = {"launches_per_step": n // n_prof, "ms_per_step": ms / n_prof,
-                          "tflops": flops / (ms * 1e-3) / 1e12 if flops else None,
-                          "algorithmic_GBs": nbytes / (ms * 1e-3) / 1e9}
-        line["kernels"] = kernels
-        # the matrix kernels by NAME: the event classes pw1 and pw2 are launches of one kernel
-        gemm_name = {"fp32": "gemm_f32_kernel", "bf16": "gemm_bf16_kernel", "bf16a": "gemm_bf16_kernel", "fp32_split": "gemm_split16_kernel"}[args.precision]
-        fused_name = {"fp32": "mlp_fused_kernel", "bf16": "mlp_fused_bf16_kernel", "bf16a": "mlp_fused_bf16_kernel", "fp32_split": "mlp_fused_split_kernel"}[args.precision]
-        groups = {gemm_name + " (pwconv1+GELU and pwconv2+residual launches, two-GEMM stages)": ("pw1", "pw2"),
-                  fused_name + " (LN+pwconv1+GELU+pwconv2+residual in one launch)": ("mlp_fused",),
-                  ("mlp_fused_wide_bf16_kernel (LN+pwconv1+GELU+pwconv2+residual in one launch, stages 0-2)" if bf16 else
-                   "mlp_fused_wide_kernel (LN+pwconv1+GELU+pwconv2+residual in one launch, stages 1-2)"): ("mlp_wide",)}
-        merged = {}
-        for name, ks in groups.items():
-            ks = [k for k in ks if k in kernels]
-            if not ks:
-                continue
-            n = sum(kernels[k]["launches_per_step"] for k in ks)
-            merged[name] = {"ms": sum(kernels[k]["ms_per_step"] for k in ks), "launches": n,
-                            "flops": sum(work[k][0] for k in ks), "bytes": sum(work[k][1] for k in ks)}
-        # split mode executes 3 fp16 MFMA flops per algorithmic fp32 flop: the algorithmic peak of that arithmetic is the
-        # dense fp16 peak / 3
-        raw_peak = MFMA_BF16_PEAK_TF if (bf16 or split) else MFMA_F32_PEAK_TF
-        mfma_mult = 3.0 if split else 1.0
-        peak = raw_peak / mfma_mult
-        dom = max(merged, key=lambda k: merged[k]["ms"])
-        g = merged[dom]
-        per_launch_flops = g["flops"] / g["launches"]
-        avg_launch_s = g["ms"] * 1e-3 / g["launches"]
-        ach = per_launch_flops / avg_launch_s / 1e12
-        traffic, traffic_src = measured_traffic()
-        if bf16:            # the committed PMC summary the bench reads is the default precision's
-            traffic, traffic_src = {}, None
-        tr = lambda k: (traffic.get(k, {}).get("hbm_traffic_bytes_per_launch") if B == 64 else None)
-        dom_classes = [k for k in groups[dom] if k in kernels]
-        tr_dom = [tr(k) for k in dom_classes]
-        tr_dom = (sum(t * kernels[k]["launches_per_step"] for t, k in zip(tr_dom, dom_classes)) / g["launches"]
-                  if all(t is not None for t in tr_dom) and not bf16 else None)
-        line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                            "frac": ach / peak, "frac_executed": mfma_mult * ach / raw_peak,
-                            "frac_algorithmic_vs_fp16_peak" if (split or bf16) else "frac_algorithmic": ach / raw_peak,
-                            "peak_note": ("dense fp16 MFMA peak %.0f TFLOP/s / %d MFMAs per fp32 product" % (raw_peak, int(mfma_mult)))
-                                         if split else "dense MFMA peak of the operand type",
-                            "traffic": tr_dom, "traffic_source": traffic_src, "avg_launch_ms": avg_launch_s * 1e3,
-                            "launches_per_step": g["launches"], "ms_per_step": g["ms"],
-                            "algorithmic_flops_per_launch": per_launch_flops,
-                            "executed_mfma_flops_per_launch": mfma_mult * per_launch_flops,
-                            "algorithmic_bytes_per_launch": g["bytes"] / g["launches"]}
-        if split:
-            pk = 1024 * 1024 * SPLIT_SHADER_CLOCK_GHZ / 1e3 / 3.0     # SIMDs x flop/cycle/SIMD x GHz / 3 -> TFLOP/s algorithmic
-            line["roofline"].update({"shader_clock_GHz_in_kernel_pmc": SPLIT_SHADER_CLOCK_GHZ,
-                                     "peak_at_that_clock": pk, "frac_at_that_clock": ach / pk})
-        if bf16:        # at bf16 rates the GEMMs are bound by their HBM traffic (the hidden activation), not the matrix pipe
-            gbs = g["bytes"] / g["launches"] / avg_launch_s / 1e9
-            if gbs / HBM_PEAK_GBS > ach / peak:
-                line["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": gbs / HBM_PEAK_GBS, "mfma_tflops": ach})
-        line["roofline_other_matrix_kernels"] = {
-            k: {"achieved": v["flops"] / (v["ms"] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, "ms_per_step": v["ms"], "launches_per_step": v["launches"]}
-            for k, v in merged.items() if k != dom}
-        mf = sum(v["flops"] for v in merged.values()) / sum(v["ms"] * 1e-3 for v in merged.values()) / 1e12
-        line["roofline_all_pointwise"] = {"bound": "mfma", "achieved": mf, "peak": peak, "unit": "TFLOP/s", "frac": mf / peak}
-        dw = kernels["dwconv"]
-        line["roofline_dwconv"] = {"kernel": "dwconv7_kernel", "bound": "hbm", "achieved": dw["algorithmic_GBs"],
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dw["algorithmic_GBs"] / HBM_PEAK_GBS,
-                                   "frac_of_copy_rate": dw["algorithmic_GBs"] / HBM_COPY_GBS, "copy_rate": HBM_COPY_GBS,
-                                   "traffic": tr("dwconv") if not bf16 else None, "traffic_source": traffic_src,
-                                   "algorithmic_bytes_per_launch": work["dwconv"][1] / dw["launches_per_step"]}
+        line.update(profile_rooflines(model, dev, fn, B, args.precision, max(1, min(args.steps, 5))))
     if rank == 0 and world == 1 and split and not args.no_profile:
         # the native f32-MFMA arithmetic on the same workload, same process (fewer steps: it is not the headline)
         model.set_precision("fp32")
@@ -488,6 +544,32 @@ def main():
         line["native_f32_mfma"] = {"value": B * n_nat / dt, "unit": "clips/s", "ms_per_step": 1e3 * dt / n_nat, "steps": n_nat,
                                    "note": "v_mfma_f32_32x32x2_f32 path (--precision fp32), same workload and process"}
         model.set_precision("fp32_split")
+    if rank == 0 and world == 1 and split and not args.no_profile and not args.no_extra_configs and args.mode == "logits" and B == 64:
+        # The other single-GPU BASELINE configs, measured in this process next to the headline:
+        #   bf16a_shard -- configs[2]'s per-rank workload (64 x 10 s, bf16 contractions + bf16 activations of stages 0-2)
+        #   frame_bs256 -- configs[3]: forward_frame_embeddings at bs = 256 ("HBM-bound depthwise path": dwconv GB/s)
+        model.set_precision("bf16a")
+        dt = timed(fn, dev, max(20, min(args.steps, 50)), 3)
+        sub = {"value": B / dt, "unit": "clips/s", "ms_per_step": 1e3 * dt, "steps": max(20, min(args.steps, 50)),
+               "dtype": "bf16 (contractions and stored activations of stages 0-2; fp32 LayerNorm statistics, accumulate, GELU, residual add)",
+               "workload": "BASELINE configs[2] per-rank shard: ConvNeXt-Tiny bs=64, 10 s @ 32 kHz, waveform -> logits, set_precision('bf16a')",
+               "sub_batches": model.native_context(dev).sub_batches(B)}
+        sub.update(profile_rooflines(model, dev, fn, B, "bf16a", 5))
+        line["bf16a_shard"] = sub
+        model.set_precision("fp32_split")
+        B2 = 256
+        wav2 = synth.synth_waveforms(B2, CLIP_SAMPLES, seed=4321).to(dev)
+        fn2 = lambda: model.forward_frame_embeddings(wav2)
+        dt = timed(fn2, dev, 5, 2)
+        sub = {"value": B2 / dt, "unit": "clips/s", "ms_per_step": 1e3 * dt, "steps": 5,
+               "workload": "BASELINE configs[3]: forward_frame_embeddings, bs=256, 10 s @ 32 kHz, output (256,768,31,7) fp32, default arithmetic",
+               "sub_batches": model.native_context(dev).sub_batches(B2)}
+        pr = profile_rooflines(model, dev, fn2, B2, "fp32_split", 2)
+        sub["roofline_dwconv"] = pr["roofline_dwconv"]
+        sub["roofline"] = pr["roofline"]
+        sub["kernels"] = {k: {"ms_per_step": v["ms_per_step"], "launches_per_step": v["launches_per_step"]} for k, v in pr["kernels"].items()}
+        line["frame_bs256"] = sub
+        del wav2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     if rank == 0:

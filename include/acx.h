@@ -61,7 +61,7 @@ enum acx_precision {
     ACX_PREC_F32 = 0,         /* v_mfma_f32_32x32x2_f32: fp32 operands on the matrix cores */
     ACX_PREC_BF16 = 1,        /* bf16 operands, fp32 accumulate (NOT within the 1e-3 bar) */
     ACX_PREC_F32_SPLIT = 2,   /* DEFAULT.  fp32 operands carried as fp16 hi + fp16 lo -- v = hi + lo + e with
-                               * |e| <= 2^-23 |v| in the worst case (exact for ~75 % of values; 22-23 significant bits
+                               * |e| <= 2^-23 |v| in the worst case (exact for ~40 % of random mantissas; 23 significant bits
                                * where fp32 has 24) -- three fp16 MFMAs per product (the lo*lo term, <= 2^-22 |ab|, is
                                * dropped), fp32 accumulate: fp32-grade results (same parity tests and
                                * tolerances as ACX_PREC_F32, plus tests/test_gpu_stress.py) at 16/3 of the f32-MFMA
