@@ -42,6 +42,7 @@ SIGNATURES = {
     "acx_downsample": (_c_int, [_vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "acx_pool_head": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp]),
     "acx_nhwc_to_nchw": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "acx_frontend_info": (_c_int, [_vp, _pint, ctypes.POINTER(ctypes.c_float), _pint]),
     "acx_tuning_refresh": (_c_int, []),
     "acx_profile_enable": (_c_int, [_vp, _c_int]),
     "acx_profile_read": (_c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64)]),
@@ -147,6 +148,12 @@ class Context:
         out = _c_int()
         check(lib().acx_sub_batches(self._h, int(B), ctypes.byref(out)))
         return out.value
+
+    def frontend_info(self):
+        """{"dense_dft": bool, "stft_deviation": float, "mel_taps": int} -- how acx_finalize evaluates the frontend."""
+        d, dev, taps = _c_int(), ctypes.c_float(), _c_int()
+        check(lib().acx_frontend_info(self._h, ctypes.byref(d), ctypes.byref(dev), ctypes.byref(taps)))
+        return {"dense_dft": bool(d.value), "stft_deviation": dev.value, "mel_taps": taps.value}
 
     def profile(self, on):
         check(lib().acx_profile_enable(self._h, 1 if on else 0))

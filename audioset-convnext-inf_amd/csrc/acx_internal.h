@@ -163,6 +163,14 @@ struct acx_ctx {
     int mel_w_len = 0;            // number of floats in d_mel_w
     float* d_bn_scale = nullptr;  // [224]
     float* d_bn_shift = nullptr;  // [224]
+    // dense-DFT fallback (STFT buffers that are not window x DFT: the two Conv1d are evaluated as one GEMM, convnext.py:179-187)
+    bool dense_stft = false;
+    float stft_deviation = 0.f;   // max |stored - hann x DFT| found at acx_finalize
+    float* d_stft_w = nullptr;    // [kDenseN][1024]: rows 0..512 conv_real, 513..1025 conv_imag, the rest zero
+    float* d_stft_zero = nullptr; // [kDenseN] zero bias
+    void* fe_scratch = nullptr;   // acx_logmel_bn0 only (the forward uses the caller's workspace): frames + spectrum, grown on demand
+    size_t fe_scratch_bytes = 0;
+    std::mutex fe_mutex;
     // stem
     float* d_stem_w = nullptr;    // [96][16]
     float* d_stem_b = nullptr;    // [96]
@@ -227,7 +235,11 @@ struct ProfScope {       // records a HIP-event pair around a launch when profil
 inline int stage_h0(int T) { return (T + 8 - 4) / 4 + 1; }
 
 // ---- kernel launchers (each returns acx_status) ---------------------------------------------
-int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s);
+// dense_frames / dense_spec: scratch of the dense-DFT fallback (B*T*1024 and B*T*kDenseN floats); null: the context's own
+// scratch, grown on demand (per-kernel entry point only: not capturable)
+constexpr int kDenseN = 1056;                    // 2 x 513 rows padded to a multiple of the GEMM's 96-column tile
+int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s,
+                  float* dense_frames = nullptr, float* dense_spec = nullptr);
 // act_bf16: the activation tensors named void* are bf16 (ACX_PREC_BF16_ACT, stages 0-2) instead of fp32
 int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, void* out, hipStream_t s, bool act_bf16 = false);
 int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, float* stats, int B, int H,

@@ -182,7 +182,8 @@ static void free_device(acx_ctx* c) {
 
 static const std::vector<float>& W(const acx_ctx* c, const std::string& k) { return c->host.at(k).data; }
 
-static int check_stft_is_hann_dft(const acx_ctx* c, std::vector<float>* hann_out) {
+// max |stored - window x DFT| with the window read from bin 0 (cos = 1: that row IS the window)
+static double stft_deviation_from_dft(const acx_ctx* c, std::vector<float>* hann_out) {
     const auto& re = W(c, "spectrogram_extractor.stft.conv_real.weight");
     const auto& im = W(c, "spectrogram_extractor.stft.conv_imag.weight");
     std::vector<float>& hann = *hann_out;
@@ -196,11 +197,7 @@ static int check_stft_is_hann_dft(const acx_ctx* c, std::vector<float>* hann_out
             worst = std::fmax(worst, std::fabs(ei - im[(size_t)k * kNFFT + n]));
         }
     }
-    if (worst > 2e-6)
-        ACX_FAIL(ACX_ERR_UNSUPPORTED,
-                 "STFT buffers are not window x DFT (max deviation %.3g): the FFT frontend cannot stand in for "
-                 "spectrogram_extractor.stft.conv_real/conv_imag", worst);
-    return ACX_OK;
+    return worst;
 }
 
 static int finalize_impl(acx_ctx* c) {
@@ -217,8 +214,24 @@ static int finalize_impl(acx_ctx* c) {
     }
 
     // ---- frontend ---------------------------------------------------------------------------
+    // The FFT stands in for the two Conv1d only if the stored buffers ARE window x DFT (any window; torchlibrosa's is the
+    // periodic hann).  The reference applies whatever its state_dict holds (convnext.py:179-187, overwritten by
+    // load_state_dict), so anything else -- a fine-tuned or hand-edited frontend -- runs as the dense contraction it is:
+    // frames [B T, 1024] . [conv_real; conv_imag]^T on the f32 matrix cores (frontend.hip).
     std::vector<float> hann;
-    ACX_TRY(check_stft_is_hann_dft(c, &hann));
+    const double dev = stft_deviation_from_dft(c, &hann);
+    c->stft_deviation = (float)dev;
+    c->dense_stft = !(dev <= 2e-6);
+    c->d_stft_w = nullptr; c->d_stft_zero = nullptr;
+    if (c->dense_stft) {
+        std::vector<float> w((size_t)kDenseN * kNFFT, 0.f);
+        const auto& re = W(c, "spectrogram_extractor.stft.conv_real.weight");
+        const auto& im = W(c, "spectrogram_extractor.stft.conv_imag.weight");
+        std::memcpy(w.data(), re.data(), (size_t)kBins * kNFFT * 4);
+        std::memcpy(w.data() + (size_t)kBins * kNFFT, im.data(), (size_t)kBins * kNFFT * 4);
+        ACX_TRY(upload(c, w, &c->d_stft_w));
+        ACX_TRY(upload(c, std::vector<float>(kDenseN, 0.f), &c->d_stft_zero));
+    }
     ACX_TRY(upload(c, hann, &c->d_hann));
     std::vector<float> tw(2 * kNFFT);
     for (int n = 0; n < kNFFT; ++n) {
@@ -692,6 +705,7 @@ void acx_destroy(acx_ctx* c) {
     for (auto& r : c->prof.recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
     for (auto& kv : c->aux) destroy_aux(kv.second.a);
+    if (c->fe_scratch) (void)hipFree(c->fe_scratch);
     delete c;
 }
 
@@ -833,7 +847,9 @@ static int forward_one(acx_ctx* c, const float* wav, int B, int64_t L, int mode,
     float* hidden = (float*)(ws + p.off_hidden);
     float* stats = (float*)(ws + p.off_stats);
 
-    ACX_TRY(launch_logmel(c, wav, B, L, p.T, feat, true, st));
+    // (dense-DFT fallback: frames in `hidden`, spectrum in `y` -- both idle until the first block, both large enough:
+    // T * 4096 <= H0 * 86016 and T * 4 kDenseN <= H0 * 21504 bytes per clip with H0 >= (T + 1) / 4)
+    ACX_TRY(launch_logmel(c, wav, B, L, p.T, feat, true, st, hidden, y));
     ACX_TRY(launch_stem(c, feat, B, p.T, p.Hs[0], x[0], st, act_bf16(c, 0)));
     for (int s = 0; s < 4; ++s) {
         // The last block of stages 0-2 writes LayerNorm(x) as GEMM operand rows (S16 / bf16) instead of x: nothing else
@@ -988,6 +1004,14 @@ int acx_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float
 int acx_nhwc_to_nchw(const float* x, float* out, int B, int H, int Wd, int C, void* stream) {
     if (!x || !out || B <= 0 || H <= 0 || Wd <= 0 || C <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_nhwc_to_nchw: bad argument");
     return launch_nhwc_to_nchw(nullptr, x, out, B, H, Wd, C, (hipStream_t)stream);
+}
+
+int acx_frontend_info(const acx_ctx* c, int* dense_dft, float* stft_deviation, int* mel_taps) {
+    ACX_TRY(need_ready(c));
+    if (dense_dft) *dense_dft = c->dense_stft ? 1 : 0;
+    if (stft_deviation) *stft_deviation = c->stft_deviation;
+    if (mel_taps) *mel_taps = c->mel_w_len;
+    return ACX_OK;
 }
 
 int acx_tuning_refresh(void) {

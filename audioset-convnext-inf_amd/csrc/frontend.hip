@@ -158,7 +158,90 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 }
 
 
-int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s) {
+// ---- dense-DFT fallback: STFT buffers that are NOT window x DFT (acx_finalize, api.hip) -----------------------------------
+// The reference evaluates spectrogram_extractor.stft.conv_real / conv_imag as two Conv1d over the reflect-padded waveform
+// whatever they hold (convnext.py:179-187, :298); when the FFT cannot stand in for them the same contraction runs as
+//   frames [B T, 1024] (reflect-padded, NO window: it is inside the stored weights) . [conv_real; conv_imag]^T -> [B T, 2 x 513]
+// on the f32-input matrix cores (gemm.hip, the native fp32 GEMM: in every precision mode the frontend stays fp32), then
+// |.|^2, the banded mel filter, dB and bn0 exactly as in logmel_kernel.
+__global__ __launch_bounds__(256) void frames_kernel(const float* __restrict__ wav, long long L, int T, long long nframes,
+                                                     float* __restrict__ frames) {
+    for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const long long b = f / T;
+        const int t = (int)(f - b * T);
+        const float* x = wav + b * L;
+        const long long p0 = 320LL * t;
+        float4 v;
+        const int n = 4 * threadIdx.x;
+        v.x = x[reflect_index(p0 + n, L)]; v.y = x[reflect_index(p0 + n + 1, L)];
+        v.z = x[reflect_index(p0 + n + 2, L)]; v.w = x[reflect_index(p0 + n + 3, L)];
+        reinterpret_cast<float4*>(frames + f * kNFFT)[threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void spec_to_logmel_kernel(const float* __restrict__ spec /*[nframes][kDenseN]*/, long long nframes,
+                                                             const int* __restrict__ mel_start, const int* __restrict__ mel_len,
+                                                             const int* __restrict__ mel_off, const float* __restrict__ mel_w,
+                                                             const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+                                                             float* __restrict__ out) {
+    __shared__ float P[kFrontWaves][kBins + 3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long f = (long long)blockIdx.x * kFrontWaves + wave; f < nframes; f += (long long)gridDim.x * kFrontWaves) {
+        const float* sp = spec + f * kDenseN;
+        for (int k = lane; k < kBins; k += 64) {
+            const float re = sp[k], im = sp[kBins + k];
+            P[wave][k] = re * re + im * im;                  // torchlibrosa: real ** 2 + imag ** 2 (power = 2.0)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int m = lane; m < kMels; m += 64) {
+            float acc = 0.f;
+            const float* p = P[wave] + mel_start[m];
+            const float* w = mel_w + mel_off[m];
+            const int n = mel_len[m];
+            for (int q = 0; q < n; ++q) acc = fmaf(p[q], w[q], acc);
+            const float db = 10.0f * log10f(fmaxf(acc, 1e-10f));
+            out[f * kMels + m] = fmaf(db, bn_scale[m], bn_shift[m]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // P is rewritten by the next frame
+    }
+}
+
+static int launch_logmel_dense(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s,
+                               float* frames, float* spec) {
+    const long long nframes = (long long)B * T;
+    if (!frames || !spec) {          // per-kernel entry point: the context's own scratch, grown on demand
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (s != nullptr && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            ACX_FAIL(ACX_ERR_STATE, "acx_logmel_bn0 (dense-DFT frontend) cannot run inside a stream capture: use acx_forward");
+        std::lock_guard<std::mutex> lock(c->fe_mutex);
+        const size_t need = (size_t)nframes * (kNFFT + kDenseN) * 4;
+        if (c->fe_scratch_bytes < need) {
+            if (c->fe_scratch) { ACX_HIP(hipDeviceSynchronize()); (void)hipFree(c->fe_scratch); c->fe_scratch = nullptr; c->fe_scratch_bytes = 0; }
+            ACX_HIP(hipMalloc(&c->fe_scratch, need));
+            c->fe_scratch_bytes = need;
+        }
+        frames = reinterpret_cast<float*>(c->fe_scratch);
+        spec = frames + (size_t)nframes * kNFFT;
+    }
+    ProfScope ps(c, ACX_K_FRONTEND, s);
+    long long blocks = nframes < 4096 ? nframes : 4096;
+    frames_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(wav, L, T, nframes, frames);
+    ACX_HIP(hipGetLastError());
+    GemmArgs g{};
+    g.A = frames; g.Wt = c->d_stft_w; g.bias = c->d_stft_zero; g.out = spec; g.M = nframes; g.N = kDenseN; g.K = kNFFT;
+    g.epi = EPI_BIAS; g.cls = -1;       // (inside this ProfScope: not a class of its own)
+    ACX_TRY(launch_gemm(nullptr, g, s));
+    blocks = (nframes + kFrontWaves - 1) / kFrontWaves;
+    if (blocks > 2048) blocks = 2048;
+    spec_to_logmel_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(spec, nframes, c->d_mel_start, c->d_mel_len, c->d_mel_off, c->d_mel_w,
+                                                                        bn ? c->d_bn_scale : c->d_bn_one, bn ? c->d_bn_shift : c->d_bn_zero, out);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
+int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s,
+                  float* dense_frames, float* dense_spec) {
+    if (c->dense_stft) return launch_logmel_dense(c, wav, B, L, T, out, bn, s, dense_frames, dense_spec);
     long long nframes = (long long)B * T;
     long long blocks = (nframes + kFrontWaves - 1) / kFrontWaves;
     // 6 workgroups per CU (3 resident): a workgroup's setup -- twiddle and mel tables into the LDS, lane twiddles into registers --

@@ -44,7 +44,7 @@ enum acx_status {
     ACX_ERR_HIP = -3,         /* a HIP runtime call failed */
     ACX_ERR_SHAPE = -4,       /* tensor shape does not match the model, or clip too short */
     ACX_ERR_WORKSPACE = -5,   /* workspace too small or misaligned */
-    ACX_ERR_UNSUPPORTED = -6  /* e.g. STFT buffers that are not hann x DFT */
+    ACX_ERR_UNSUPPORTED = -6  /* e.g. a device that is not gfx950 */
 };
 
 enum acx_mode {
@@ -102,9 +102,9 @@ ACX_API int acx_set_weight(acx_ctx* ctx, const char* state_dict_key, const float
                    const int64_t* shape, int ndim);
 
 /* Folds and repacks for the kernels, uploads to the device:
- *   bn0 -> per-mel scale/shift (convnext.py:304-306); melW -> banded form; verifies that the
- *   STFT buffers are hann x DFT (else ACX_ERR_UNSUPPORTED) so that the FFT kernel may stand in
- *   for the two Conv1d (convnext.py:179-187,298);
+ *   bn0 -> per-mel scale/shift (convnext.py:304-306); melW -> banded form (any matrix: a band may span all 513 bins);
+ *   STFT buffers that are window x DFT (torchlibrosa's are hann x DFT) -> the FFT kernel stands in for the two Conv1d
+ *   (convnext.py:179-187,298); any other stored buffers -> the dense contraction itself (acx_frontend_info);
  *   dwconv (C,1,7,7) -> [49][C]; LayerNorm affine of each block folded into pwconv1;
  *   gamma folded into pwconv2 (convnext.py:78-83); downsample conv (C',C,2,2) -> [C'][4C] with its
  *   LayerNorm affine folded in.
@@ -171,6 +171,13 @@ ACX_API int acx_pool_head(acx_ctx* ctx, const float* x, int B, int H3, float* sc
                   float* probs, void* stream);
 /* NHWC -> NCHW (the layout forward_frame_embeddings returns, convnext.py:276-277). */
 ACX_API int acx_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, void* stream);
+
+/* How acx_finalize decided to evaluate the frontend: *dense_dft = 0 when the stored STFT buffers are window x DFT (max
+ * deviation *stft_deviation <= 2e-6) and the FFT kernel stands in for the two Conv1d, 1 when they are not and the
+ * contraction runs as stored (GEMM on the f32 matrix cores) -- the reference applies whatever its state_dict holds
+ * (convnext.py:179-187); *mel_taps = stored taps of the banded form of melW (884 for librosa's bank, up to 513 x 224 for a
+ * dense matrix, which is applied as it is).  Any pointer may be NULL. */
+ACX_API int acx_frontend_info(const acx_ctx* ctx, int* dense_dft, float* stft_deviation, int* mel_taps);
 
 /* Diagnostics.  The tile-shape A/B switches ACX_GEMM_MI, ACX_WIDE_NPB, ACX_GEMM_32X32 and ACX_DW_STREAM are read from the
  * environment once, at the first acx_create; this re-reads them (tests force every tile shape through it and require

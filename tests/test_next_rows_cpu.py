@@ -182,3 +182,32 @@ def test_ahead_reader_thread_stops_when_the_consumer_leaves_early():
         raise ValueError("boom")
     with pytest.raises(ValueError, match="boom"):
         list(ev._ahead(bad(), lambda x: x))
+
+
+def test_verify_checkpoint_tool(tmp_path, synth_sd):
+    """tools/verify_checkpoint.py (SURVEY 8c's pin for the day a real checkpoint arrives): exit 0 on a checkpoint that carries
+    this package's own tables, 1 when a buffer deviates by more than the tolerance, 2 when one is missing -- for both
+    checkpoint formats the reference ships (.safetensors, .pth with {"model": sd})."""
+    import os
+    import subprocess
+    import sys
+    from safetensors.torch import save_file
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify_checkpoint.py")
+    good = str(tmp_path / "model.safetensors")
+    save_file({k: v.contiguous() for k, v in synth_sd.items()}, good)
+    r = subprocess.run([sys.executable, tool, good], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "runs the FFT frontend" in r.stdout and "884 taps" in r.stdout and "frontend tables pinned" in r.stdout
+    bad = dict(synth_sd)
+    bad["logmel_extractor.melW"] = synth_sd["logmel_extractor.melW"] + 1e-4
+    pth = str(tmp_path / "bad.pth")
+    torch.save({"model": bad}, pth)
+    r = subprocess.run([sys.executable, tool, pth], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "DEVIATES" in r.stdout and "frontend tables DIFFER" in r.stdout
+    worse = dict(synth_sd)
+    worse["spectrogram_extractor.stft.conv_real.weight"] = synth_sd["spectrogram_extractor.stft.conv_real.weight"] * 1.001
+    del worse["logmel_extractor.melW"]
+    pth2 = str(tmp_path / "worse.pth")
+    torch.save(worse, pth2)
+    r = subprocess.run([sys.executable, tool, pth2], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "missing buffers" in r.stdout
