@@ -27,6 +27,7 @@ void tuning_reload() {
     t.wide_npb.store(digit("ACX_WIDE_NPB", "12", 0), std::memory_order_relaxed);
     t.gemm_32x32.store(digit("ACX_GEMM_32X32", "1", 0), std::memory_order_relaxed);
     t.dw_stream.store(digit("ACX_DW_STREAM", "01", -1), std::memory_order_relaxed);
+    t.fail_sub.store(digit("ACX_TEST_FAIL_SUB", "0123", -1), std::memory_order_relaxed);
 }
 
 void set_error(const char* fmt, ...) {
@@ -920,6 +921,10 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
                              out1 ? out1 + b_off * per_clip : nullptr, ws + ws_off, pi, si);
             ws_off += pi.total;
             b_off += Bi;
+            if (rc == ACX_OK && tuning().fail_sub.load(std::memory_order_relaxed) == i) {
+                set_error("test hook ACX_TEST_FAIL_SUB: failure injected after sub-batch %d", i);
+                rc = ACX_ERR_STATE;
+            }
         }
         tls_inflight_ways = 1;
         for (int i = 1; i <= forked; ++i) {            // join whatever was forked, also after an error

@@ -76,3 +76,63 @@ def test_demo_script(tmp_path):
     assert "Scene embedding, shape: torch.Size([1, 768])" in out
     assert "Frame-level embeddings, shape: torch.Size([1, 768, 31, 7])" in out   # padded to 10 s
     assert "Padding waveform" in out and "label " in out
+
+
+def test_demo_script_probabilities_match_the_oracle(tmp_path):
+    """not only the shapes -- the probabilities demo_convnext.py prints for the labels above its
+    threshold are the oracle's for the same clip and weights (printed to 3 decimals)."""
+    import re
+    from oracle import ref_cpu
+    rs = np.random.RandomState(3)
+    t = np.arange(5 * 32000) / 32000.0
+    clip = (0.3 * np.sin(2 * np.pi * 440.0 * t) + 0.05 * rs.standard_normal(t.size)).astype(np.float32)
+    wav = str(tmp_path / "tone.wav")
+    ut.write_wav_pcm16(wav, clip, 32000, list_chunk=False)
+    labels = tmp_path / "labels.csv"
+    labels.write_text("index,mid,display_name\n" + "".join('%d,/m/%04d,"label %d"\n' % (i, i, i) for i in range(527)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "demo_convnext.py"), "--synthetic-weights", "--wav", wav,
+                        "--labels", str(labels), "--threshold", "0.5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    printed = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"^label (\d+): ([0-9.]+)$", r.stdout, flags=re.M)}
+    assert len(printed) >= 5, r.stdout[-1500:]
+    pcm, sr = ut.read_wav_pcm16(wav)
+    x = ut.prepare_clip(torch.from_numpy(pcm[:1]), sr, 32000, 10)
+    probs = ref_cpu.forward(synth.synth_state_dict(0), x)["clipwise_output"][0]
+    above = set(int(i) for i in np.where(probs.numpy() > 0.5)[0])
+    # the same label set up to probabilities within rounding distance of the threshold, the same values to 3 decimals (+ 1e-3 parity)
+    edge = set(int(i) for i in np.where(np.abs(probs.numpy() - 0.5) < 2e-3)[0])
+    assert set(printed) - edge == above - edge
+    for i, p in printed.items():
+        assert abs(p - float(probs[i])) < 1.6e-3, (i, p, float(probs[i]))
+
+
+def test_evaluate_script_synthetic_sweep(model, synth_sd):
+    """evaluate_convnext_on_audioset.py itself (not only its callees): `--synthetic 300` prints the three
+    `Validate <set> <metric>` lines of the reference (evaluate_convnext_on_audioset.py:77-85); the numbers equal the statistics of
+    the same shard scored in this process, whose probabilities in turn match the oracle on a few clips."""
+    import importlib.util
+    import re
+    from oracle import ref_cpu
+    from audioset_convnext_inf_amd.pytorch.evaluate import calculate_statistics
+    script = os.path.join(ROOT, "evaluate_convnext_on_audioset.py")
+    r = subprocess.run([sys.executable, script, "--synthetic", "300", "--batch_size", "64"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = {k: float(v) for k, v in re.findall(r"^Validate synthetic (mAP|AUC|d-prime): ([0-9.\-]+)$", r.stdout, flags=re.M)}
+    assert set(got) == {"mAP", "AUC", "d-prime"}, r.stdout[-1500:]
+    assert "total_params 28222767" in r.stdout and "300 clips in" in r.stdout
+    spec = importlib.util.spec_from_file_location("eval_script", script)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    shard = mod.synthetic_shard(300)
+    scores = []
+    for i in range(0, 300, 60):
+        w = torch.from_numpy((shard.waveforms[i:i + 60] / 32767.0).astype(np.float32)).cuda()
+        scores.append(model(w)["clipwise_output"].cpu().numpy())
+    scores = np.concatenate(scores)
+    st = calculate_statistics(np.asarray(shard.targets[:300], dtype=np.float32), scores)
+    assert abs(got["mAP"] - float(np.mean(st["average_precision"]))) < 2e-3
+    assert abs(got["AUC"] - float(np.mean(st["auc"]))) < 2e-3
+    assert abs(got["d-prime"] - float(np.mean(st["d_prime"]))) < 5e-3
+    w4 = torch.from_numpy((shard.waveforms[:3] / 32767.0).astype(np.float32))
+    ref = ref_cpu.forward(synth_sd, w4)["clipwise_output"]
+    assert float((torch.from_numpy(scores[:3]) - ref).abs().max()) < 1e-3

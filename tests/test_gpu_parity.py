@@ -405,3 +405,59 @@ def test_e2e_odd_and_long_clips(model, synth_sd, L):
     assert out["clipwise_logits"].shape == (1, 527) and fr.shape == (1, 768, h3, w3)
     assert maxdiff(out["clipwise_logits"], ref["clipwise_logits"]) < E2E_TOL
     assert maxdiff(fr, ref_cpu.forward_frame_embeddings(synth_sd, wav)) < E2E_TOL
+
+
+def test_default_capture_stream_at_split_batch_sizes(model):
+    """`with torch.cuda.graph(g): model(x)` captures on torch's private capture stream, which nobody can warm up.
+    A batch that would run as two sub-batches finds no fork / join set for that stream inside the capture: it runs un-split
+    there (same bits, include/acx.h) instead of failing."""
+    wav = synth.synth_waveforms(18, 16000, seed=12).cuda()
+    eager = model(wav)["clipwise_logits"].clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = model(wav)["clipwise_logits"]
+    torch.cuda.synchronize()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+
+
+def test_failure_in_a_sub_batch_joins_the_forked_streams(model, monkeypatch):
+    """an error while queueing sub-batch 1 must not leave the side stream un-joined -- inside a stream
+    capture an un-joined fork invalidates the capture (hipErrorStreamCaptureUnjoined at capture end), and the caller may free
+    the workspace the side stream still uses.  The failure is injected by a test hook (ACX_TEST_FAIL_SUB, read by
+    acx_tuning_refresh); the capture must END cleanly, and the model must work afterwards."""
+    refresh = _ffi.lib().acx_tuning_refresh
+    wav = synth.synth_waveforms(17, 16000, seed=13).cuda()
+    good = model(wav)["clipwise_logits"].clone()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):            # the stream gets its fork / join set here: the captures below DO split
+        model(wav)
+    torch.cuda.synchronize()
+    try:
+        for sub in ("0", "1"):
+            monkeypatch.setenv("ACX_TEST_FAIL_SUB", sub)
+            refresh()
+            with pytest.raises(_ffi.AcxError, match="ACX_TEST_FAIL_SUB"):        # eager
+                model(wav)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(s):
+                raised = False
+                with torch.cuda.graph(g, stream=s):
+                    try:
+                        model(wav)
+                    except _ffi.AcxError:
+                        raised = True
+                assert raised                                                    # ... and leaving the `with` did not raise: the fork was joined
+            torch.cuda.synchronize()
+    finally:
+        monkeypatch.delenv("ACX_TEST_FAIL_SUB", raising=False)
+        refresh()
+    with torch.cuda.stream(s):
+        again = model(wav)["clipwise_logits"]
+    torch.cuda.synchronize()
+    assert torch.equal(again, good)
