@@ -668,7 +668,7 @@ static int launch_dw_tile(const BlockW& w, int C, const void* x, void* y, int B,
 // halo rows and their prologue: one wave per SIMD of the CUs this launch may count on (all of them, or its share while
 // acx_forward runs several sub-batches side by side).  Same bits either way (same accumulation order per output element);
 // ACX_DW_STREAM = 0 | 1 forces a form (tests).
-static bool use_col_kernel(const acx_ctx* c, int B, int H, int W, int* target_waves) {
+static bool use_col_kernel(const acx_ctx* c, int B, int H, int W, bool act_bf16, int* target_waves) {
     if (!c || !c->d_dw_sink) return false;
     const int force = tuning().dw_stream.load(std::memory_order_relaxed);
     if (force == 0) return false;
@@ -676,9 +676,11 @@ static bool use_col_kernel(const acx_ctx* c, int B, int H, int W, int* target_wa
     if (cu_count_of_current_device(&cus) != ACX_OK) return false;
     *target_waves = 4 * cus / inflight_ways();
     if (force == 1) return true;
-    if (W == 7) return false;                         // stage 3: 13 rows per wave at B = 64 -- the tile kernel
+    // rows of the stacked batch per wave segment (dwconv_col.hip: one wave per SIMD in the fp32 stages 0-1, two elsewhere)
     const long long Vt = (long long)B * (H + 3) - 3;
-    return Vt / (*target_waves / 6 > 0 ? *target_waves / 6 : 1) >= (W == 14 ? 20 : 40);
+    const bool two = act_bf16 || W <= 14;
+    const long long segs = (long long)*target_waves * (two ? 2 : 1) / 6;
+    return Vt / (segs > 0 ? segs : 1) >= (two ? (W == 7 ? 6 : 10) : 40);
 }
 
 int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, float* stats, int B, int H,
@@ -687,7 +689,7 @@ int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, fl
     {
         ProfScope ps(c, ACX_K_DWCONV, s);
         int rc, target_waves = 0;
-        if (C == 96 * 56 / (W > 0 ? W : 1) && !(W == 7 && act_bf16) && use_col_kernel(c, B, H, W, &target_waves)) {
+        if (C == 96 * 56 / (W > 0 ? W : 1) && !(W == 7 && act_bf16) && use_col_kernel(c, B, H, W, act_bf16, &target_waves)) {
             rc = launch_dwconv_col(x, y, w.dw, w.dwb, c->d_dw_sink, B, H, W, act_bf16, target_waves, s);
             ACX_TRY(rc);
             if (stats) ACX_TRY(launch_rowstats(c, reinterpret_cast<const float*>(y), stats, (int64_t)B * H * W, C, s));

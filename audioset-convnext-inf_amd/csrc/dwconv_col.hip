@@ -36,7 +36,10 @@ namespace acx {
 typedef float dwc_f32x2 __attribute__((ext_vector_type(2)));
 typedef float dwc_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int W, bool BF>
+// R: rows of the wave's ring.  7 = the phases of the accumulator rotation: slot addresses are immediates of the unrolled loop
+// (one wave per SIMD has the LDS for it).  Smaller rings -- two waves per SIMD, 20 KB of LDS each -- walk their slots with two
+// running byte offsets.
+template <int W, bool BF, int R = 7>
 struct DwColCfg {
     static constexpr int kC = 96 * 56 / W;                        // channels of the stage with this width
     static constexpr int kStrips = W >= 28 ? 4 : W / 7;           // strips of 7 output pixels per wave (16 lanes each)
@@ -54,8 +57,8 @@ struct DwColCfg {
     static constexpr int kPiecesPerSlice = (kReal + kSPP - 1) / kSPP;
     static constexpr int kPieces = kSlices * kPiecesPerSlice;
     static constexpr int kRowB = kSlices * kSlots * kSlotB;       // bytes of a ring row
-    static constexpr int kRing = 7;                               // = phases of the accumulator rotation
-    static constexpr int kD = BF ? 6 : 5;                         // rows in flight ahead of the one being multiplied
+    static constexpr int kRing = R;
+    static constexpr int kD = (BF ? 6 : 5) < R - 1 ? (BF ? 6 : 5) : R - 1;   // rows in flight ahead of the one being multiplied
     // Every step issues exactly kPieces DMAs and 7 stores (invalid ones go to a sink), in that order behind its wait:
     // the row of step t was requested at step t - kD, followed by that step's 7 stores and kD - 1 whole steps.
     static constexpr int kWait = 7 + (kD - 1) * (kPieces + 7);
@@ -126,7 +129,7 @@ __device__ __forceinline__ void dwc_issue_pieces(const char* src, const unsigned
 }
 
 // One input row: phase I of the rotation (static), ring slot I, kernel rows KLO .. KHI (static).
-//   rd      LDS address of this lane's first input column in ring slot 0
+//   rowp    LDS address of this lane's first input column in the row's ring slot
 //   real    the row is inside an image (wave-uniform): otherwise it contributes nothing
 // A segment's first six input rows only meet the kernel rows whose output row lies inside the segment (KHI = 0 .. 5), its
 // last six likewise (KLO = 1 .. 6): the halo rows of a segment cost their loads, not their FMAs -- and the kernel-row range is
@@ -136,12 +139,11 @@ __device__ __forceinline__ void dwc_issue_pieces(const char* src, const unsigned
 // column is first needed 7+ FMAs after the one before it: the wave waits for the first LDS read only; an accumulator returns
 // after >= 7 other FMAs).  For one output element that is kernel column 0 .. 6 -- the order of dwconv.hip.
 template <int W, bool BF, int I, int KLO, int KHI>
-__device__ __forceinline__ void dwc_row(DwColState<W, BF>& st, const char* rd, bool real) {
+__device__ __forceinline__ void dwc_row(DwColState<W, BF>& st, const char* rowp, bool real) {
     using Cfg = DwColCfg<W, BF>;
     constexpr int slot0 = (I + 6) % 7;            // the output row that starts here (kernel row 0)
     if (real) {
         dwc_f32x2 in[13];
-        const char* rowp = rd + I * Cfg::kRowB;
 #pragma unroll
         for (int j = 0; j < 13; ++j) {
             if (W == 7 && (j < 3 || j > 9)) continue;           // columns outside the image: zero, taps skipped
@@ -176,13 +178,14 @@ __device__ __forceinline__ void dwc_row(DwColState<W, BF>& st, const char* rd, b
     }
 }
 
-template <int W, bool BF>
-__global__ __launch_bounds__(256, 1) void dwconv7_col_kernel(const void* __restrict__ x_, void* __restrict__ y_,
+template <int W, bool BF, int R, int WPS>
+__global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __restrict__ x_, void* __restrict__ y_,
                                                              const float* __restrict__ wt /*[49][C]*/,
                                                              const float* __restrict__ bias, void* __restrict__ sink_,
                                                              int B, int H, int k7 /* output rows per segment / 7 */, int n_items,
                                                              unsigned magic /* floor(2^32 / (H + 3)) + 1 */) {
-    using Cfg = DwColCfg<W, BF>;
+    using Cfg = DwColCfg<W, BF, R>;
+    static_assert(Cfg::kLdsBytes * WPS <= 160 * 1024, "the rings of a CU's waves do not fit the LDS");
     constexpr int C = Cfg::kC, kEsz = Cfg::kEsz, D = Cfg::kD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void dwconv7_col_kernel(const void* __restr
     // prologue is one memory latency, not two (weights first cost 7 k cycles per wave before the first row was even requested).
     if constexpr (Cfg::kHalo > 0) {
         constexpr int kChunks = Cfg::kSlotB / 16;                              // 16-byte chunks per slot
-        constexpr int kZ = 7 * Cfg::kSlices * 2 * Cfg::kHalo * kChunks;      // chunks to zero
+        constexpr int kZ = R * Cfg::kSlices * 2 * Cfg::kHalo * kChunks;      // chunks to zero
         for (int i = lane; i < kZ; i += 64) {
             const int c = i % kChunks, s6 = (i / kChunks) % (2 * Cfg::kHalo), rs = i / kChunks / (2 * Cfg::kHalo);
             const int slot = s6 < Cfg::kHalo ? s6 : Cfg::kPx + s6;              // 0, 1, 2, kPx + 3, kPx + 4, kPx + 5
@@ -273,17 +276,18 @@ __global__ __launch_bounds__(256, 1) void dwconv7_col_kernel(const void* __restr
     // Every step requests a row (the counted wait relies on it); a step whose row is not part of an image re-requests the
     // wave's latest real row (from the cache) -- never one address for all waves: that serialises in one L2 channel.
     const char* safe_src = pf_ptr;
-#define ACX_DWC_PREFETCH(bit_, slot_)                                                                           \
+    unsigned cur_off = 0, pf_off = (unsigned)(D * Cfg::kRowB);      // R < 7: ring offsets of the row being read / requested
+#define ACX_DWC_PREFETCH(bit_, off_)                                                                            \
     {                                                                                                           \
         const bool real_ = (rmask >> (bit_)) & 1u;                                                              \
         const char* src_ = real_ ? pf_ptr : safe_src;                                                           \
         safe_src = src_;                                                                                        \
         pf_ptr += real_ ? Cfg::kGRowB : 0;                                                                      \
-        dwc_issue_pieces<W, BF, 0>(src_, voff, ring_lds + (unsigned)((slot_) * Cfg::kRowB), first_real);        \
+        dwc_issue_pieces<W, BF, 0>(src_, voff, ring_lds + (off_), first_real);                                  \
     }
     ACX_DWC_FLAGS(0)
 #pragma unroll
-    for (int i = 0; i < D; ++i) ACX_DWC_PREFETCH(i + 3, i)
+    for (int i = 0; i < D; ++i) ACX_DWC_PREFETCH(i + 3, (unsigned)(i * Cfg::kRowB))
     ACX_DWC_STAMP(1)
 #pragma unroll
     for (int t = 0; t < 49; ++t) st.wt[t] = *reinterpret_cast<const dwc_f32x2*>(wt + t * C + ch);
@@ -298,8 +302,12 @@ __global__ __launch_bounds__(256, 1) void dwconv7_col_kernel(const void* __restr
 #define ACX_DWC_STEP(I_, KLO_, KHI_)                                                                            \
     {                                                                                                           \
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ACX_DWC_ABLATE >= 2 ? 0 : Cfg::kWait) : "memory");           \
-        ACX_DWC_PREFETCH((I_) + D + 3, ((I_) + D) % 7)                                                          \
-        dwc_row<W, BF, I_, KLO_, KHI_>(st, rd, (rmask >> ((I_) + 3)) & 1u);                                     \
+        ACX_DWC_PREFETCH((I_) + D + 3, (R == 7 ? (unsigned)((((I_) + D) % 7) * Cfg::kRowB) : pf_off))           \
+        dwc_row<W, BF, I_, KLO_, KHI_>(st, rd + (R == 7 ? (unsigned)((I_) * Cfg::kRowB) : cur_off), (rmask >> ((I_) + 3)) & 1u); \
+        if (R != 7) {                                                                                           \
+            cur_off = cur_off + Cfg::kRowB == (unsigned)Cfg::kWaveLds ? 0u : cur_off + Cfg::kRowB;              \
+            pf_off = pf_off + Cfg::kRowB == (unsigned)Cfg::kWaveLds ? 0u : pf_off + Cfg::kRowB;                 \
+        }                                                                                                       \
         const bool out_ok_ = (omask >> (I_)) & 1u;                                                              \
         char* dst_ = (out_ok_ ? out_ptr : sink) + yoff;                                                         \
         out_ptr += out_ok_ ? Cfg::kGRowB : 0;                                                                   \
@@ -331,38 +339,43 @@ __global__ __launch_bounds__(256, 1) void dwconv7_col_kernel(const void* __restr
 // target_waves: how many waves the launch should consist of (one per SIMD of the CUs it may use).  Every wave takes a
 // segment of 7 k output rows of the stacked batch (the rotation has seven phases: the first and the last six steps then sit at
 // fixed phases and are compiled with their reduced kernel-row ranges).
-template <int W, bool BF>
+template <int W, bool BF, int R, int WPS>
 static int launch_dw_col_cfg(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H,
                              int target_waves, hipStream_t s) {
-    using Cfg = DwColCfg<W, BF>;
+    using Cfg = DwColCfg<W, BF, R>;
     const long long Vt = (long long)B * (H + 3) - 3;
     // exactness of v / (H + 3) by multiply-high needs (stacked rows + 9 (H + 3) + slack) * (H + 3) < 2^32
     if ((Vt + 16ll * (H + 3) + 64) * (H + 3) >= 0xffffffffll)
         ACX_FAIL(ACX_ERR_SHAPE, "dwconv7: batch too tall for one launch (%d clips of %d rows)", B, H);
-    long long segs = target_waves / Cfg::kUnits;
+    long long segs = (long long)target_waves * WPS / Cfg::kUnits;
     if (segs < 1) segs = 1;
     long long k7 = (Vt + 7 * segs - 1) / (7 * segs);                   // ceil(rows per segment / 7)
-    if (k7 < (kDwColMinRows + 6) / 7) k7 = (kDwColMinRows + 6) / 7;
+    const long long kmin = WPS == 2 ? 1 : (kDwColMinRows + 6) / 7;
+    if (k7 < kmin) k7 = kmin;
     const long long n_seg = (Vt + 7 * k7 - 1) / (7 * k7);
     const int n_items = (int)(n_seg * Cfg::kUnits);
     static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &dwconv7_col_kernel<W, BF>, Cfg::kLdsBytes));
-    dwconv7_col_kernel<W, BF><<<dim3((unsigned)((n_items + 3) / 4)), dim3(256), Cfg::kLdsBytes, s>>>(
+    ACX_TRY(set_max_dynamic_lds(once, &dwconv7_col_kernel<W, BF, R, WPS>, Cfg::kLdsBytes));
+    dwconv7_col_kernel<W, BF, R, WPS><<<dim3((unsigned)((n_items + 3) / 4)), dim3(256), Cfg::kLdsBytes, s>>>(
         x, y, wt, bias, sink, B, H, (int)k7, n_items, (unsigned)(0x100000000ull / (unsigned)(H + 3)) + 1u);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
 
+// Occupancy by stage: the HBM-bound stages 0-1 in fp32 run one wave per SIMD (long segments: few halo rows, a deep ring);
+// wherever the FMAs are what takes the time -- the cache-resident stages 2-3, and every stage once the activations are bf16 --
+// two waves per SIMD (a second wave fills the issue slots a lone wave leaves: v_pk_fma_f32 issues every 5 cycles from one
+// wave, every 4 from two) on half-length segments, whose extra halo rows come from the cache or weigh half.
 int launch_dwconv_col(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H, int W,
                       bool act_bf16, int target_waves, hipStream_t s) {
     switch (W) {
-        case 56: return act_bf16 ? launch_dw_col_cfg<56, true>(x, y, wt, bias, sink, B, H, target_waves, s)
-                                 : launch_dw_col_cfg<56, false>(x, y, wt, bias, sink, B, H, target_waves, s);
-        case 28: return act_bf16 ? launch_dw_col_cfg<28, true>(x, y, wt, bias, sink, B, H, target_waves, s)
-                                 : launch_dw_col_cfg<28, false>(x, y, wt, bias, sink, B, H, target_waves, s);
-        case 14: return act_bf16 ? launch_dw_col_cfg<14, true>(x, y, wt, bias, sink, B, H, target_waves, s)
-                                 : launch_dw_col_cfg<14, false>(x, y, wt, bias, sink, B, H, target_waves, s);
-        case 7: if (!act_bf16) return launch_dw_col_cfg<7, false>(x, y, wt, bias, sink, B, H, target_waves, s);
+        case 56: return act_bf16 ? launch_dw_col_cfg<56, true, 7, 2>(x, y, wt, bias, sink, B, H, target_waves, s)
+                                 : launch_dw_col_cfg<56, false, 7, 1>(x, y, wt, bias, sink, B, H, target_waves, s);
+        case 28: return act_bf16 ? launch_dw_col_cfg<28, true, 7, 2>(x, y, wt, bias, sink, B, H, target_waves, s)
+                                 : launch_dw_col_cfg<28, false, 7, 1>(x, y, wt, bias, sink, B, H, target_waves, s);
+        case 14: return act_bf16 ? launch_dw_col_cfg<14, true, 7, 2>(x, y, wt, bias, sink, B, H, target_waves, s)
+                                 : launch_dw_col_cfg<14, false, 4, 2>(x, y, wt, bias, sink, B, H, target_waves, s);
+        case 7: if (!act_bf16) return launch_dw_col_cfg<7, false, 5, 2>(x, y, wt, bias, sink, B, H, target_waves, s);
                 ACX_FAIL(ACX_ERR_STATE, "dwconv7: stage 3 keeps fp32 activations");
         default: ACX_FAIL(ACX_ERR_SHAPE, "dwconv7: unsupported width %d (expected 56/28/14/7)", W);
     }

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <random>
 #include <vector>
+#include <algorithm>
 
 #include "dwconv.hip"
 #include "dwconv_col.hip"
@@ -103,6 +104,14 @@ static void stamp_case(int B, int H, int W, int waves) {
     double avg[7] = {0};
     CK(hipMemset(x, 0, 64));
     for (int i = 0; i < 4096; ++i) if (st[i * 8 + 6]) for (int k = 0; k < 7; ++k) avg[k] += (double)(st[i * 8 + k] - st[i * 8]) / items;
+    {
+        std::vector<double> life, startoff;
+        for (int i = 0; i < 4096; ++i) if (st[i * 8 + 6]) { life.push_back((double)(st[i * 8 + 6] - st[i * 8])); startoff.push_back((double)(st[i * 8] - t0)); }
+        std::sort(life.begin(), life.end()); std::sort(startoff.begin(), startoff.end());
+        printf("W=%d: lifetime k cycles min %.1f median %.1f p90 %.1f max %.1f | start offset median %.1f p90 %.1f max %.1f | first start -> last end %.1f\n", W,
+               life.front() / 1e3, life[life.size() / 2] / 1e3, life[life.size() * 9 / 10] / 1e3, life.back() / 1e3,
+               startoff[startoff.size() / 2] / 1e3, startoff[startoff.size() * 9 / 10] / 1e3, startoff.back() / 1e3, (t6 - t0) / 1e3);
+    }
     printf("W=%d B=%d: %d waves; mean stamp (k cycles from the wave's own start):", W, B, items);
     const char* names[7] = {"start", "prologue issued", "first rows landed", "group 0 done", "main loop done", "epilogue done", "stores drained"};
     for (int k = 0; k < 7; ++k) printf("  %s %.1f", names[k], avg[k] / 1e3);
