@@ -87,19 +87,6 @@ __device__ unsigned long long acx_dwc_stamps[4096 * 8];
 #define ACX_DWC_PKFMA(acc_, a_, b_) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc_) : "v"(a_), "v"(b_))
 #define ACX_DWC_PKFMA_INIT(acc_, a_, b_, c_) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "+v"(acc_) : "v"(a_), "v"(b_), "v"(c_))
 
-// one 1-KB piece: lanes of `mask` fetch 16 bytes each from base + voff into lds + 16 lane
-template <unsigned long long MASK>
-__device__ __forceinline__ void dwc_piece(const char* base, unsigned voff, unsigned lds) {
-    if constexpr (MASK == ~0ull) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :: "s"(lds), "v"(voff), "s"(base) : "memory");
-    } else {
-        unsigned long long keep;
-        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %4\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
-                     : "=&s"(keep) : "s"(lds), "v"(voff), "s"(base), "s"(MASK) : "memory");
-    }
-}
-
 template <int W, bool BF>
 struct DwColState {
     dwc_f32x2 acc[7][7];      // [phase slot][pixel]
@@ -117,14 +104,59 @@ constexpr unsigned long long dwc_mask() {
     return m;
 }
 
+// A row's pieces in ONE statement with ONE M0 write: the immediate offset of global_load_lds moves the LDS destination AND the
+// source by the same amount (split_math.h, acx_glds16_run), so piece p is issued with its LDS distance from piece 0 as the
+// immediate, and its lane offsets are stored with that distance taken out again (+ kDwcAdj, which the base pointer gives back:
+// the offsets stay non-negative).  Full pieces first, then EXEC is narrowed once for the partial ones (their lanes beyond the
+// image stay out: those LDS slots hold zeros or the next slice).  6-8 instructions per row instead of 14.
+constexpr int kDwcAdj = 4096;
 template <int W, bool BF, int P>
-__device__ __forceinline__ void dwc_issue_pieces(const char* src, const unsigned (&voff)[DwColCfg<W, BF>::kPieces], unsigned lds_row, int first_real) {
+constexpr int dwc_piece_lds_off() {          // LDS distance of piece P from piece 0
     using Cfg = DwColCfg<W, BF>;
-    if constexpr (P < Cfg::kPieces) {
-        constexpr int sl = P / Cfg::kPiecesPerSlice, k = P % Cfg::kPiecesPerSlice;
-        const unsigned lds = lds_row + (unsigned)(sl * Cfg::kSlots * Cfg::kSlotB + k * 1024) + (unsigned)first_real * Cfg::kSlotB;
-        if (ACX_DWC_ABLATE != 2) dwc_piece<dwc_mask<W, BF, k>()>(src, voff[P], lds);
-        dwc_issue_pieces<W, BF, P + 1>(src, voff, lds_row, first_real);
+    return (P / Cfg::kPiecesPerSlice) * Cfg::kSlots * Cfg::kSlotB + (P % Cfg::kPiecesPerSlice) * 1024;
+}
+template <int W, bool BF>
+__device__ __forceinline__ void dwc_issue_row(const char* src, const unsigned (&voff)[DwColCfg<W, BF>::kPieces], unsigned lds0) {
+    using Cfg = DwColCfg<W, BF>;
+    if (ACX_DWC_ABLATE == 2) return;
+    const char* base = src - kDwcAdj;
+    constexpr int kLast = Cfg::kPiecesPerSlice - 1;
+    constexpr unsigned long long kMask = dwc_mask<W, BF, kLast>();          // the partial piece(s): the last of every slice
+    static_assert(kMask != ~0ull, "every layout ends its slices with a partial piece");
+    unsigned long long keep;
+    if constexpr (Cfg::kPieces == 4 && Cfg::kSlices == 1) {                 // W = 56 / 28 fp32: 0 1 2 full, 3 partial
+        asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, exec\n\t"
+                     "global_load_lds_dwordx4 %2, %6 offset:%c7\n\tglobal_load_lds_dwordx4 %3, %6 offset:%c8\n\tglobal_load_lds_dwordx4 %4, %6 offset:%c9\n\t"
+                     "s_mov_b64 exec, %11\n\tglobal_load_lds_dwordx4 %5, %6 offset:%c10\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "s"(lds0), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(base),
+                       "n"(dwc_piece_lds_off<W, BF, 0>()), "n"(dwc_piece_lds_off<W, BF, 1>()), "n"(dwc_piece_lds_off<W, BF, 2>()), "n"(dwc_piece_lds_off<W, BF, 3>()),
+                       "s"(kMask) : "memory");
+    } else if constexpr (Cfg::kPieces == 4 && Cfg::kSlices == 2) {          // W = 14 fp32: 0, 2 full; 1, 3 partial
+        asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, exec\n\t"
+                     "global_load_lds_dwordx4 %2, %6 offset:%c7\n\tglobal_load_lds_dwordx4 %4, %6 offset:%c9\n\t"
+                     "s_mov_b64 exec, %11\n\tglobal_load_lds_dwordx4 %3, %6 offset:%c8\n\tglobal_load_lds_dwordx4 %5, %6 offset:%c10\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "s"(lds0), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(base),
+                       "n"(dwc_piece_lds_off<W, BF, 0>()), "n"(dwc_piece_lds_off<W, BF, 1>()), "n"(dwc_piece_lds_off<W, BF, 2>()), "n"(dwc_piece_lds_off<W, BF, 3>()),
+                       "s"(kMask) : "memory");
+    } else if constexpr (Cfg::kPieces == 4) {                               // W = 7: four slices, one partial piece each
+        asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, %11\n\t"
+                     "global_load_lds_dwordx4 %2, %6 offset:%c7\n\tglobal_load_lds_dwordx4 %3, %6 offset:%c8\n\t"
+                     "global_load_lds_dwordx4 %4, %6 offset:%c9\n\tglobal_load_lds_dwordx4 %5, %6 offset:%c10\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "s"(lds0), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(base),
+                       "n"(dwc_piece_lds_off<W, BF, 0>()), "n"(dwc_piece_lds_off<W, BF, 1>()), "n"(dwc_piece_lds_off<W, BF, 2>()), "n"(dwc_piece_lds_off<W, BF, 3>()),
+                       "s"(kMask) : "memory");
+    } else if constexpr (Cfg::kPieces == 2 && Cfg::kSlices == 1) {          // W = 56 / 28 bf16: 0 full, 1 partial
+        asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, exec\n\t"
+                     "global_load_lds_dwordx4 %2, %4 offset:%c5\n\t"
+                     "s_mov_b64 exec, %7\n\tglobal_load_lds_dwordx4 %3, %4 offset:%c6\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "s"(lds0), "v"(voff[0]), "v"(voff[1]), "s"(base),
+                       "n"(dwc_piece_lds_off<W, BF, 0>()), "n"(dwc_piece_lds_off<W, BF, 1>()), "s"(kMask) : "memory");
+    } else {                                                                // W = 14 bf16: two slices, one partial piece each
+        static_assert(Cfg::kPieces == 2 && Cfg::kSlices == 2, "piece layout");
+        asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, %7\n\t"
+                     "global_load_lds_dwordx4 %2, %4 offset:%c5\n\tglobal_load_lds_dwordx4 %3, %4 offset:%c6\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "s"(lds0), "v"(voff[0]), "v"(voff[1]), "s"(base),
+                       "n"(dwc_piece_lds_off<W, BF, 0>()), "n"(dwc_piece_lds_off<W, BF, 1>()), "s"(kMask) : "memory");
     }
 }
 
@@ -190,8 +222,8 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int item = (int)blockIdx.x * 4 + wave;
-    if (item >= n_items) return;                      // (no barrier in this kernel: a wave may leave alone)
+    // (a wave past the last item repeats it -- identical stores: no early exit, so that every kernel argument is loaded at once)
+    const int item = min((int)blockIdx.x * 4 + wave, n_items - 1);
     ACX_DWC_STAMP(0)
     const int unit = item % Cfg::kUnits, seg = item / Cfg::kUnits;
     const int half = unit % Cfg::kHalves, sg = unit / Cfg::kHalves;
@@ -217,7 +249,8 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
         const int sl = p / Cfg::kPiecesPerSlice, k = p % Cfg::kPiecesPerSlice;
         int col = col_base + first_real + k * Cfg::kSPP + lane / Cfg::kLanesPerSlot;
         col = col < 0 ? 0 : (col >= W ? W - 1 : col);                 // masked lanes: any valid address
-        voff[p] = (unsigned)((col * C + cbase + sl * 32) * kEsz + (lane % Cfg::kLanesPerSlot) * 16);
+        voff[p] = (unsigned)((col * C + cbase + sl * 32) * kEsz + (lane % Cfg::kLanesPerSlot) * 16) +
+                  (unsigned)(kDwcAdj - (sl * Cfg::kSlots * Cfg::kSlotB + k * 1024));          // see dwc_issue_row
     }
 
     // ---- the segment: 7 k7 output rows [vb, ve) of the stacked image (stacked row v = clip * (H + 3) + row; row >= H: one of
@@ -230,12 +263,12 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
     const char* pf_ptr;                                             // next in-image row at or after the prefetch cursor
     {
         const int v0 = vb - 3 + Hp;                                 // >= 0
-        const int n1 = v0 / Hp, r0 = v0 - n1 * Hp;
+        const int n1 = (int)__umulhi((unsigned)v0, magic), r0 = v0 - n1 * Hp;
         pf_ptr = x0 + ((long long)(n1 - 1) * H + (r0 < H ? r0 : H)) * Cfg::kGRowB;
     }
     char* out_ptr;                                                  // next in-image output row at or after vb
     {
-        const int n = vb / Hp, r = vb - n * Hp;
+        const int n = (int)__umulhi((unsigned)vb, magic), r = vb - n * Hp;
         out_ptr = reinterpret_cast<char*>(y_) + ((long long)n * H + (r < H ? r : H)) * Cfg::kGRowB;
     }
     // Stores of rows that are not this wave's (the six steps above its segment, the rows between clips) go to a sink.  Every wave
@@ -283,7 +316,7 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
         const char* src_ = real_ ? pf_ptr : safe_src;                                                           \
         safe_src = src_;                                                                                        \
         pf_ptr += real_ ? Cfg::kGRowB : 0;                                                                      \
-        dwc_issue_pieces<W, BF, 0>(src_, voff, ring_lds + (off_), first_real);                                  \
+        dwc_issue_row<W, BF>(src_, voff, ring_lds + (off_) + (unsigned)(first_real * Cfg::kSlotB));             \
     }
     ACX_DWC_FLAGS(0)
 #pragma unroll
