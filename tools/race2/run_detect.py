@@ -7,7 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 V = os.path.join(ROOT, "build", "variants")
 dets = {}
-for name in ("packed", "scalar"):
+for name in ("packed", "scalar", "pkmuladd"):      # pkmuladd (round 4): -ffp-contract=off -- v_pk_mul_f32 / v_pk_add_f32 only, no v_pk_fma_f32
+    if not os.path.isfile(os.path.join(V, "libdetector_%s.so" % name)):
+        continue
     d = ctypes.CDLL(os.path.join(V, "libdetector_%s.so" % name))
     d.detector_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     d.detector_launch_lds.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -57,6 +59,11 @@ def detect(name, sp):
     assert dets[name].detector_launch_lds(seed.data_ptr(), o.data_ptr(), VB, ROUNDS, DET_LDS, sp) == 0
     return o
 refs = {n: detect(n, null_sp) for n in dets}; torch.cuda.synchronize()
+# round 4: a REAL packed-FP32 victim of the library itself -- the column-streaming depthwise kernel (343 v_pk_fma_f32 per row and
+# lane, LDS-DMA, 122 KB of LDS per workgroup: it shares a CU with nothing that needs more than 38 KB)
+vx = torch.randn(16, HS[0], WS[0], DIMS[0], device="cuda"); vy = torch.empty_like(vx); vref = torch.empty_like(vx)
+os.environ["ACX_DW_STREAM"] = "1"; lib.acx_tuning_refresh()
+lib.acx_dwconv7(h, 0, 1, _ffi.ptr(vx), _ffi.ptr(vref), None, 16, HS[0], WS[0], null_sp); torch.cuda.synchronize()
 for what in sys.argv[1:]:
     load = make_load(what)
     res = []
@@ -70,5 +77,14 @@ for what in sys.argv[1:]:
             torch.cuda.synchronize()
             nb = int((o != refs[n]).sum()); bad_thr += nb; bad_runs += int(nb > 0)
         res.append("%s detector wrong in %d/5 runs (%d threads)" % (n, bad_runs, bad_thr))
+    bad_runs = bad_el = 0
+    for it in range(5):
+        torch.cuda.synchronize()
+        load()
+        with torch.cuda.stream(side):
+            lib.acx_dwconv7(h, 0, 1, _ffi.ptr(vx), _ffi.ptr(vy), None, 16, HS[0], WS[0], side_sp)
+        torch.cuda.synchronize()
+        nb = int((vy != vref).sum()); bad_el += nb; bad_runs += int(nb > 0)
+    res.append("dwconv7_col victim wrong in %d/5 runs (%d elements)" % (bad_runs, bad_el))
     print("DETECT det_lds=%d lib=%s prec=%s aggressor=%-12s %s" % (DET_LDS, os.path.basename(os.environ.get("ACX_LIB", "libacx.so")),
                                                         os.environ.get("ACX_PRECISION", "fp32_split"), what, "; ".join(res)), flush=True)
