@@ -42,6 +42,10 @@ SIGNATURES = {
     "acx_downsample": (_c_int, [_vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "acx_pool_head": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp]),
     "acx_nhwc_to_nchw": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "acx_comm_unique_id": (_c_int, [_vp]),
+    "acx_comm_init": (_c_int, [_vp, _c_int, _c_int, _vp]),
+    "acx_allgather": (_c_int, [_vp, _vp, _vp, _c_sz, _vp]),
+    "acx_comm_info": (_c_int, [_vp, _pint, _pint]),
     "acx_frontend_info": (_c_int, [_vp, _pint, ctypes.POINTER(ctypes.c_float), _pint]),
     "acx_tuning_refresh": (_c_int, []),
     "acx_profile_enable": (_c_int, [_vp, _c_int]),
@@ -148,6 +152,25 @@ class Context:
         out = _c_int()
         check(lib().acx_sub_batches(self._h, int(B), ctypes.byref(out)))
         return out.value
+
+    # ---- the C ABI's own collective (include/acx.h): RCCL all-gather without torch.distributed ----
+    @staticmethod
+    def comm_unique_id():
+        buf = ctypes.create_string_buffer(128)
+        check(lib().acx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        check(lib().acx_comm_init(self._h, int(rank), int(world), ctypes.c_char_p(unique_id)))
+
+    def allgather(self, local):
+        """(n, ...) contiguous device tensor -> (world * n, ...) in rank order, on the current stream."""
+        import torch
+        r, w = _c_int(), _c_int()
+        check(lib().acx_comm_info(self._h, ctypes.byref(r), ctypes.byref(w)))
+        out = torch.empty((w.value * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        check(lib().acx_allgather(self._h, ptr(local), ptr(out), local.numel() * local.element_size(), stream_ptr(local.device)))
+        return out
 
     def frontend_info(self):
         """{"dense_dft": bool, "stft_deviation": float, "mel_taps": int} -- how acx_finalize evaluates the frontend."""

@@ -202,11 +202,15 @@ struct acx_ctx {
     // identity affine for acx_logmel_bn0(apply_bn0 = 0) (tests): per context, i.e. per device
     float* d_bn_one = nullptr;
     float* d_bn_zero = nullptr;
+    void* comm = nullptr;          // RCCL communicator (comm.hip), owned; null until acx_comm_init
+    int comm_rank = 0, comm_world = 1;
     void* d_dw_sink = nullptr;     // kDwSinkBytes: where the column-streaming depthwise kernel stores rows that are not image rows
     acx::Profile prof;
 };
 
 namespace acx {
+
+void comm_release(acx_ctx* c);     // comm.hip
 
 // Sub-batches of the forward THIS THREAD is queueing (acx_forward): the tile-shape choice of a small launch counts the
 // workgroups of the other sub-batches too.  Per thread, not per context: concurrent forwards on one context from several

@@ -706,6 +706,7 @@ void acx_destroy(acx_ctx* c) {
     for (auto& r : c->prof.recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
     for (auto& kv : c->aux) destroy_aux(kv.second.a);
+    comm_release(c);
     if (c->fe_scratch) (void)hipFree(c->fe_scratch);
     delete c;
 }

@@ -140,6 +140,22 @@ ACX_API int acx_sub_batches(const acx_ctx* ctx, int B, int* out);
 ACX_API int acx_forward(acx_ctx* ctx, const float* wav, int B, int64_t L, int mode, float* out0,
                 float* out1, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- multi-GPU: the one collective of the path -----------------------------------------------------------------
+ * One process per GPU, full weight replica, clips sharded; logits / probabilities / scene rows are all-gathered over xGMI by
+ * RCCL (ncclAllGather), frame embeddings stay sharded.  The reference has no inference-time collective (training DDP only,
+ * main.py:641,992-997); the Python host reaches the same collective through torch.distributed (parallel.py).  librccl.so is
+ * opened on first use: a single-GPU process never loads it.
+ *   rank 0: acx_comm_unique_id(id) -> share the ACX_COMM_ID_BYTES bytes with every rank (file, TCP store, MPI ...)
+ *   all   : acx_comm_init(ctx, rank, world, id)         (collective: every rank must call it)
+ *   step  : acx_allgather(ctx, send, recv, bytes_per_rank, stream)   recv = world * bytes_per_rank device bytes, rank order;
+ *           enqueued on `stream` behind the forward that produced `send` -- no host synchronisation.
+ * The communicator belongs to the context (released by acx_destroy). */
+#define ACX_COMM_ID_BYTES 128
+ACX_API int acx_comm_unique_id(void* id_out);
+ACX_API int acx_comm_init(acx_ctx* ctx, int rank, int world, const void* unique_id);
+ACX_API int acx_allgather(acx_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+ACX_API int acx_comm_info(const acx_ctx* ctx, int* rank, int* world);
+
 /* ---- per-kernel entry points (golden-vector tests, rocprofv3 isolation, roofline bench) ---- */
 
 /* K1: Spectrogram + LogmelFilterBank + bn0 (convnext.py:298-306). out (B,T,224). */
