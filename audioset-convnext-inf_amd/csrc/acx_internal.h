@@ -1,6 +1,7 @@
 // Internal declarations shared by the libacx translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <atomic>
 #include <cstdarg>
@@ -231,11 +232,25 @@ struct Tuning {
 Tuning& tuning();
 void tuning_reload();
 
-struct ProfScope {       // records a HIP-event pair around a launch when profiling is on
-    acx_ctx* ctx; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+// Per-kernel-class device time (acx_profile_enable / acx_profile_read).  A ProfScope names the class of the launches made on
+// this thread while it is alive; when profiling is on, every launch_kernel() inside it is dispatched with a start / stop event
+// pair of its own (hipExtLaunchKernel: the events carry the dispatch's begin and end timestamps -- the kernel's duration as
+// rocprofv3 reports it; a hipEventRecord pair AROUND a launch also times the dispatch gap in front of the kernel, 3.6 us per
+// launch on this part, 10-16 % of a 25-40 us depthwise launch).  Off: a plain launch, nothing recorded.
+struct ProfScope {
+    acx_ctx* ctx; int cls; hipStream_t s; ProfScope* prev;
     ProfScope(acx_ctx* c, int k, hipStream_t st);
     ~ProfScope();
 };
+void prof_next_events(hipEvent_t* a, hipEvent_t* b);       // api.hip: null / null unless a profiling ProfScope is open on this thread
+
+template <typename K, typename... Args>
+inline void launch_kernel(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+    hipEvent_t a = nullptr, b = nullptr;
+    prof_next_events(&a, &b);
+    if (a && b) hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, s, a, b, 0u, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+}
 
 inline int stage_h0(int T) { return (T + 8 - 4) / 4 + 1; }
 

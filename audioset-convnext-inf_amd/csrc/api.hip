@@ -37,21 +37,29 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-ProfScope::ProfScope(acx_ctx* c, int k, hipStream_t st) : ctx(c), cls(k), s(st) {
-    if (!ctx || !ctx->prof.on) { ctx = nullptr; return; }
+static thread_local ProfScope* g_prof_scope = nullptr;
+
+ProfScope::ProfScope(acx_ctx* c, int k, hipStream_t st) : ctx(c), cls(k), s(st), prev(g_prof_scope) {
+    if (!ctx || !ctx->prof.on || cls < 0) ctx = nullptr;      // (an inner scope without a class keeps the outer one's)
+    if (ctx) g_prof_scope = this;
+}
+ProfScope::~ProfScope() {
+    if (ctx) g_prof_scope = prev;
+}
+
+void prof_next_events(hipEvent_t* a, hipEvent_t* b) {
+    ProfScope* sc = g_prof_scope;
+    if (!sc) return;
+    acx_ctx* ctx = sc->ctx;
     auto get = [&]() {
         hipEvent_t e;
         if (!ctx->prof.pool.empty()) { e = ctx->prof.pool.back(); ctx->prof.pool.pop_back(); }
         else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
         return e;
     };
-    a = get(); b = get();
-    if (a) (void)hipEventRecord(a, s);
-}
-ProfScope::~ProfScope() {
-    if (!ctx) return;
-    if (b) (void)hipEventRecord(b, s);
-    ctx->prof.recs.push_back({cls, a, b});
+    *a = get(); *b = get();
+    if (!*a || !*b) { if (*a) ctx->prof.pool.push_back(*a); if (*b) ctx->prof.pool.push_back(*b); *a = *b = nullptr; return; }
+    ctx->prof.recs.push_back({sc->cls, *a, *b});
 }
 
 struct KeySpec { std::string key; std::vector<int64_t> shape; };

@@ -438,10 +438,10 @@ static int launch_rows(acx_ctx* c, const float* x, float* out, int64_t M, int C,
     ProfScope ps(c, ACX_K_ROWSTATS, s);
     dim3 grid((unsigned)blocks), blk(256);
     switch (C) {
-        case 96: rowstats_kernel<8, NORMALIZE><<<grid, blk, 0, s>>>(x, out, M, 1e-6f); break;
-        case 192: rowstats_kernel<16, NORMALIZE><<<grid, blk, 0, s>>>(x, out, M, 1e-6f); break;
-        case 384: rowstats_kernel<32, NORMALIZE><<<grid, blk, 0, s>>>(x, out, M, 1e-6f); break;
-        case 768: rowstats_kernel<64, NORMALIZE><<<grid, blk, 0, s>>>(x, out, M, 1e-6f); break;
+        case 96: launch_kernel(&rowstats_kernel<8, NORMALIZE>, grid, blk, 0, s, x, out, M, 1e-6f); break;
+        case 192: launch_kernel(&rowstats_kernel<16, NORMALIZE>, grid, blk, 0, s, x, out, M, 1e-6f); break;
+        case 384: launch_kernel(&rowstats_kernel<32, NORMALIZE>, grid, blk, 0, s, x, out, M, 1e-6f); break;
+        case 768: launch_kernel(&rowstats_kernel<64, NORMALIZE>, grid, blk, 0, s, x, out, M, 1e-6f); break;
         default: ACX_FAIL(ACX_ERR_SHAPE, "rowstats: unsupported channel count %d", C);
     }
     ACX_HIP(hipGetLastError());
@@ -490,7 +490,7 @@ static int launch_dw_cfg(const BlockW& w, int C, const void* x, void* y, int B, 
     if (n_seg > tiles_h / 2) n_seg = tiles_h / 2;
     if (n_seg < 1) n_seg = 1;
     const long long blocks = columns * n_seg;
-    dwconv7_kernel<TW, TH, BF><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(
+    launch_kernel(&dwconv7_kernel<TW, TH, BF>, dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s,
         x, y, w.dw, w.dwb, B, H, W, C, tiles_w, tiles_h, n_seg, (unsigned)(0x100000000ull / (unsigned)(H + 3)) + 1u);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
@@ -659,7 +659,7 @@ static int launch_dw_tile(const BlockW& w, int C, const void* x, void* y, int B,
     }
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &dwconv7_tile_kernel<W, BF>, Cfg::kLdsBytes));
-    dwconv7_tile_kernel<W, BF><<<dim3((unsigned)(B * per_clip)), dim3(256), Cfg::kLdsBytes, s>>>(x, y, w.dw, w.dwb, H, C, tiles_h);
+    launch_kernel(&dwconv7_tile_kernel<W, BF>, dim3((unsigned)(B * per_clip)), dim3(256), Cfg::kLdsBytes, s, x, y, w.dw, w.dwb, H, C, tiles_h);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

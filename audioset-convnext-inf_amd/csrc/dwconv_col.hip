@@ -389,7 +389,7 @@ static int launch_dw_col_cfg(const void* x, void* y, const float* wt, const floa
     const int n_items = (int)(n_seg * Cfg::kUnits);
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &dwconv7_col_kernel<W, BF, R, WPS>, Cfg::kLdsBytes));
-    dwconv7_col_kernel<W, BF, R, WPS><<<dim3((unsigned)((n_items + 3) / 4)), dim3(256), Cfg::kLdsBytes, s>>>(
+    launch_kernel(&dwconv7_col_kernel<W, BF, R, WPS>, dim3((unsigned)((n_items + 3) / 4)), dim3(256), Cfg::kLdsBytes, s,
         x, y, wt, bias, sink, B, H, (int)k7, n_items, (unsigned)(0x100000000ull / (unsigned)(H + 3)) + 1u);
     ACX_HIP(hipGetLastError());
     return ACX_OK;

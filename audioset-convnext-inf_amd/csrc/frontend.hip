@@ -225,7 +225,7 @@ static int launch_logmel_dense(acx_ctx* c, const float* wav, int B, int64_t L, i
     }
     ProfScope ps(c, ACX_K_FRONTEND, s);
     long long blocks = nframes < 4096 ? nframes : 4096;
-    frames_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(wav, L, T, nframes, frames);
+    launch_kernel(&frames_kernel, dim3((unsigned)blocks), dim3(256), 0, s, wav, L, T, nframes, frames);
     ACX_HIP(hipGetLastError());
     GemmArgs g{};
     g.A = frames; g.Wt = c->d_stft_w; g.bias = c->d_stft_zero; g.out = spec; g.M = nframes; g.N = kDenseN; g.K = kNFFT;
@@ -233,7 +233,7 @@ static int launch_logmel_dense(acx_ctx* c, const float* wav, int B, int64_t L, i
     ACX_TRY(launch_gemm(nullptr, g, s));
     blocks = (nframes + kFrontWaves - 1) / kFrontWaves;
     if (blocks > 2048) blocks = 2048;
-    spec_to_logmel_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(spec, nframes, c->d_mel_start, c->d_mel_len, c->d_mel_off, c->d_mel_w,
+    launch_kernel(&spec_to_logmel_kernel, dim3((unsigned)blocks), dim3(256), 0, s, spec, nframes, c->d_mel_start, c->d_mel_len, c->d_mel_off, c->d_mel_w,
                                                                         bn ? c->d_bn_scale : c->d_bn_one, bn ? c->d_bn_shift : c->d_bn_zero, out);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
@@ -248,7 +248,7 @@ int launch_logmel(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* 
     // is paid once per ~10 frames of a wave (with 4 096 workgroups it was once per 4: 184 -> 167 us at B = 64)
     if (blocks > 1536) blocks = 1536;
     ProfScope ps(c, ACX_K_FRONTEND, s);
-    logmel_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(wav, L, T, nframes, c->d_hann, c->d_twiddle,
+    launch_kernel(&logmel_kernel, dim3((unsigned)blocks), dim3(256), 0, s, wav, L, T, nframes, c->d_hann, c->d_twiddle,
                                                                 c->d_mel_start, c->d_mel_len, c->d_mel_off,
                                                                 c->d_mel_w, c->mel_w_len, bn ? c->d_bn_scale : c->d_bn_one,
                                                                 bn ? c->d_bn_shift : c->d_bn_zero, out);

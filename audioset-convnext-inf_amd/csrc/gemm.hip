@@ -375,7 +375,8 @@ static int launch_cfg(const GemmParams& p0, hipStream_t s) {
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm: grid too large");
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER, DW>, gemm_lds_bytes<kBM, BN>()));
-    gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER, DW><<<dim3((unsigned)blocks), dim3(256 + 64 * DW), gemm_lds_bytes<kBM, BN>(), s>>>(p);
+    constexpr size_t lds = gemm_lds_bytes<kBM, BN>();
+    launch_kernel(&gemm_f32_kernel<kBM, BN, WM, WN, EPI, GATHER, DW>, dim3((unsigned)blocks), dim3(256 + 64 * DW), lds, s, p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

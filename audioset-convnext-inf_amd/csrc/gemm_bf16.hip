@@ -239,7 +239,7 @@ static int launch_bf_cfg(const GemmBfParams& p0, hipStream_t s) {
     constexpr size_t lds = kCuLdsBytes;          // all of it: CU-exclusive
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER>, lds));
-    gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(64 * WM * WN), lds, s>>>(p);
+    launch_kernel(&gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER>, dim3((unsigned)blocks), dim3(64 * WM * WN), lds, s, p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

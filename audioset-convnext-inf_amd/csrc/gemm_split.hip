@@ -609,7 +609,7 @@ static int launch_s16_cfg(const GemmSParams& p0, hipStream_t s) {
     constexpr size_t lds = kCuLdsBytes;          // all of it: CU-exclusive
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &gemm_split16_kernel<EPI, GATHER, MI>, lds));
-    gemm_split16_kernel<EPI, GATHER, MI><<<dim3((unsigned)blocks), dim3(512), lds, s>>>(p);
+    launch_kernel(&gemm_split16_kernel<EPI, GATHER, MI>, dim3((unsigned)blocks), dim3(512), lds, s, p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
@@ -640,7 +640,7 @@ static int launch_s_cfg(const GemmSParams& p0, hipStream_t s) {
     constexpr size_t lds = kCuLdsBytes;          // all of it: CU-exclusive (see the header comment)
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER>, lds));
-    gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER><<<dim3((unsigned)blocks), dim3(64 * WM * WN), lds, s>>>(p);
+    launch_kernel(&gemm_split_kernel<kBM, BN, WM, WN, EPI, GATHER>, dim3((unsigned)blocks), dim3(64 * WM * WN), lds, s, p);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

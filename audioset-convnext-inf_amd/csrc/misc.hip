@@ -106,7 +106,7 @@ __global__ __launch_bounds__(768) void pool_head_kernel(const float* __restrict_
 int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
                      hipStream_t s) {
     ProfScope ps(c, ACX_K_POOLHEAD, s);
-    pool_head_kernel<<<dim3(B), dim3(768), 0, s>>>(x, H3, c->d_norm_w, c->d_norm_b, c->d_head_w, c->d_head_b,
+    launch_kernel(&pool_head_kernel, dim3(B), dim3(768), 0, s, x, H3, c->d_norm_w, c->d_norm_b, c->d_head_w, c->d_head_b,
                                                    scene, logits, probs);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
@@ -139,7 +139,7 @@ int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, in
     if (C % 32 != 0) ACX_FAIL(ACX_ERR_SHAPE, "nhwc_to_nchw: C=%d is not a multiple of 32", C);
     const int P = H * W;
     ProfScope ps(c, ACX_K_TRANSPOSE, s);
-    nhwc_to_nchw_kernel<<<dim3((P + 31) / 32, C / 32, B), dim3(256), 0, s>>>(x, out, P, C);
+    launch_kernel(&nhwc_to_nchw_kernel, dim3((P + 31) / 32, C / 32, B), dim3(256), 0, s, x, out, P, C);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
@@ -163,7 +163,7 @@ int launch_convert_f32_to_bf16(const float* in, void* out, long long n, hipStrea
     const long long n4 = n / 4;
     if (n4 == 0) return ACX_OK;
     const long long blocks = (n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096;
-    f32_to_bf16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, reinterpret_cast<__bf16*>(out), n4);
+    launch_kernel(&f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, reinterpret_cast<__bf16*>(out), n4);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
@@ -172,7 +172,7 @@ int launch_convert_bf16_to_f32(const void* in, float* out, long long n, hipStrea
     const long long n4 = n / 4;
     if (n4 == 0) return ACX_OK;
     const long long blocks = (n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096;
-    bf16_to_f32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(reinterpret_cast<const __bf16*>(in), out, n4);
+    launch_kernel(&bf16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const __bf16*>(in), out, n4);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

@@ -222,7 +222,7 @@ static int launch_fused_cfg(const BlockW& w, const float* y, float* x, long long
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_kernel<C>, Cfg::kLdsBytes));
     const long long blocks = (M + Cfg::kPix - 1) / Cfg::kPix;
-    mlp_fused_kernel<C><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s>>>(y, x, w.wpack, w.b1, w.b2, M);
+    launch_kernel(&mlp_fused_kernel<C>, dim3((unsigned)blocks), dim3(Cfg::kThreads), Cfg::kLdsBytes, s, y, x, w.wpack, w.b1, w.b2, M);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }

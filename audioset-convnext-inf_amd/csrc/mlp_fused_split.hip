@@ -519,7 +519,7 @@ static int launch_fused_s_cfg(const BlockW& w, const float* y, float* x, long lo
     int cus = 0;
     ACX_TRY(cu_count_of_current_device(&cus));
     const long long blocks = ntiles < cus ? ntiles : cus;      // persistent: one workgroup per CU walks the tiles
-    mlp_fused_split_kernel<C, LNOUT><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* all of it: CU-exclusive */, s>>>(
+    launch_kernel(&mlp_fused_split_kernel<C, LNOUT>, dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* all of it: CU-exclusive */, s,
         y, x, reinterpret_cast<const char*>(w.wpack_s), w.b1, w.b2, M, 1.0f / (kSplitLnScale * w.w1s_scale),
         1.0f / (w.hid_scale * w.w2s_scale), w.hid_scale, reinterpret_cast<char*>(ln_out), (int)ntiles);
     ACX_HIP(hipGetLastError());

@@ -524,7 +524,7 @@ static int launch_wide_cfg(const BlockW& w, const float* y, float* x, long long 
     ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_kernel<C, PT, LNOUT, NPB>, kCuLdsBytes));
     constexpr int kPixT = Cfg::kWaves * 16 * NPB;
     const long long blocks = (M + kPixT - 1) / kPixT;
-    mlp_fused_wide_kernel<C, PT, LNOUT, NPB><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s>>>(
+    launch_kernel(&mlp_fused_wide_kernel<C, PT, LNOUT, NPB>, dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s,
         y, x, reinterpret_cast<const char*>(w.wstream_s), w.b1, w.b2, M, 1.0f / (kSplitLnScale * w.w1s_scale),
         1.0f / (w.hid_scale * w.w2s_scale), w.hid_scale, reinterpret_cast<char*>(ln_out));
     ACX_HIP(hipGetLastError());

@@ -409,7 +409,7 @@ static int launch_wide_bf16_cfg(const BlockW& w, const void* y, void* x, long lo
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_bf16_kernel<C, PT, LNOUT, ABF>, kCuLdsBytes));
     const long long blocks = (M + Cfg::kPix - 1) / Cfg::kPix;
-    mlp_fused_wide_bf16_kernel<C, PT, LNOUT, ABF><<<dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s>>>(
+    launch_kernel(&mlp_fused_wide_bf16_kernel<C, PT, LNOUT, ABF>, dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s,
         y, x, reinterpret_cast<const char*>(w.wstream_b), w.b1, w.b2, M, ld_out, reinterpret_cast<__bf16*>(ln_out));
     ACX_HIP(hipGetLastError());
     return ACX_OK;
@@ -670,7 +670,7 @@ static int launch_stat_bf16(const BlockW& w, const void* y, void* x, long long M
     ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_stat_bf16_kernel<LNOUT, ABF>, kCuLdsBytes));
     const long long wgs_needed = ((M + 31) / 32 + 7) / 8;
     const long long blocks = wgs_needed < cu_count() ? wgs_needed : cu_count();
-    mlp_fused_stat_bf16_kernel<LNOUT, ABF><<<dim3((unsigned)blocks), dim3(512), kCuLdsBytes /* CU-exclusive */, s>>>(
+    launch_kernel(&mlp_fused_stat_bf16_kernel<LNOUT, ABF>, dim3((unsigned)blocks), dim3(512), kCuLdsBytes /* CU-exclusive */, s,
         y, x, reinterpret_cast<const char*>(w.wstream_b), w.b1, w.b2, M, ld_out, reinterpret_cast<__bf16*>(ln_out));
     ACX_HIP(hipGetLastError());
     return ACX_OK;

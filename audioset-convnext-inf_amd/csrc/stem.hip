@@ -126,10 +126,10 @@ int launch_stem(acx_ctx* c, const float* in, int B, int T, int H0, void* out, hi
     long long blocks = nrows < 2048 ? nrows : 2048;     // 8 resident workgroups per CU, every workgroup walks ~8 rows at B = 64
     ProfScope ps(c, ACX_K_STEM, s);
     if (act_bf16)
-        stem_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, T, H0, nrows, c->d_stem_w, c->d_stem_b,
+        launch_kernel(&stem_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, in, T, H0, nrows, c->d_stem_w, c->d_stem_b,
                                                                         c->d_stem_lnw, c->d_stem_lnb, out);
     else
-        stem_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, T, H0, nrows, c->d_stem_w, c->d_stem_b,
+        launch_kernel(&stem_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, in, T, H0, nrows, c->d_stem_w, c->d_stem_b,
                                                                          c->d_stem_lnw, c->d_stem_lnb, out);
     ACX_HIP(hipGetLastError());
     return ACX_OK;

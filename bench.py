@@ -29,7 +29,9 @@ Extra objects on that line:
                   (Both only at N = 1 with the default arithmetic; --no-extra-configs skips them.)
   roofline     -- the dominant KERNEL (by device time; the event classes pw1 + pw2 are one kernel,
                   gemm_split_kernel, and are merged): algorithmic FLOPs per launch / average launch duration (HIP
-                  events on the launch stream, taken in a separate profiled pass of the same workload so that
+                  events on the launch stream -- every launch of the profiled pass is dispatched with a start / stop event pair of
+                  its own (hipExtLaunchKernel), so a duration is the dispatch's begin-to-end time, the figure rocprofv3
+                  --kernel-trace reports -- taken in a separate profiled pass of the same workload so that
                   event overhead stays out of `value`; that pass runs the batch un-split on one stream, so that a launch's
                   duration is the kernel's own and not its wait for CUs the other sub-batch holds).  In fp32_split arithmetic every algorithmic fp32 flop is
                   three fp16 MFMA flops, so `peak` is the dense fp16 matrix peak / 3 (833 TFLOP/s algorithmic);

@@ -17,8 +17,9 @@ void set_error(const char* fmt, ...) {
 }
 thread_local int tls_inflight_ways = 1;
 Tuning& tuning() { static Tuning t; return t; }
-ProfScope::ProfScope(acx_ctx*, int k, hipStream_t st) : ctx(nullptr), cls(k), s(st) {}
+ProfScope::ProfScope(acx_ctx*, int k, hipStream_t st) : ctx(nullptr), cls(k), s(st), prev(nullptr) {}
 ProfScope::~ProfScope() {}
+void prof_next_events(hipEvent_t*, hipEvent_t*) {}
 }  // namespace acx
 using namespace acx;
 
