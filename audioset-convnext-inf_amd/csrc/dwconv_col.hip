@@ -239,6 +239,11 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
     const int strip = g4 % Cfg::kStrips, sl_i = g4 / Cfg::kStrips;
     const int ch = cbase + sl_i * 32 + 2 * l16;
     DwColState<W, BF> st;
+    // The 49 + 1 weight loads go out first -- 220 cycles of issue; their round trip then runs under the index arithmetic, the halo
+    // zeroing and the issue of the first rows (nothing below touches them before the rows have been requested) ...
+#pragma unroll
+    for (int t = 0; t < 49; ++t) st.wt[t] = *reinterpret_cast<const dwc_f32x2*>(wt + t * C + ch);
+    st.bias = *reinterpret_cast<const dwc_f32x2*>(bias + ch);
     const char* const rd = ring + sl_i * Cfg::kSlots * Cfg::kSlotB + strip * 7 * Cfg::kSlotB + l16 * (BF ? 4 : 8);
     const unsigned yoff = (unsigned)(((half * Cfg::kPx + strip * 7) * C + ch) * kEsz);
 
@@ -322,9 +327,7 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
 #pragma unroll
     for (int i = 0; i < D; ++i) ACX_DWC_PREFETCH(i + 3, (unsigned)(i * Cfg::kRowB))
     ACX_DWC_STAMP(1)
-#pragma unroll
-    for (int t = 0; t < 49; ++t) st.wt[t] = *reinterpret_cast<const dwc_f32x2*>(wt + t * C + ch);
-    st.bias = *reinterpret_cast<const dwc_f32x2*>(bias + ch);
+    // ... and are first used here
 #pragma unroll
     for (int a = 0; a < 7; ++a)
 #pragma unroll
