@@ -675,9 +675,10 @@ static bool use_col_kernel(const acx_ctx* c, int B, int H, int W, bool act_bf16,
     int cus = 0;
     if (cu_count_of_current_device(&cus) != ACX_OK) return false;
     *target_waves = 4 * cus / inflight_ways();
+    const long long Vt = (long long)B * (H + 3) - 3;
+    if ((Vt + 16ll * (H + 3) + 64) * (H + 3) >= 0xffffffffll) return false;   // beyond the multiply-high division of the column kernel: the ring kernel chunks
     if (force == 1) return true;
     // rows of the stacked batch per wave segment (dwconv_col.hip: one wave per SIMD in the fp32 stages 0-1, two elsewhere)
-    const long long Vt = (long long)B * (H + 3) - 3;
     const bool two = act_bf16 || W <= 14;
     const long long segs = (long long)*target_waves * (two ? 2 : 1) / 6;
     return Vt / (segs > 0 ? segs : 1) >= (two ? (W == 7 ? 6 : 10) : 40);

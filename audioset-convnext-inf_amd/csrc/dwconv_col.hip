@@ -210,7 +210,10 @@ __device__ __forceinline__ void dwc_row(DwColState<W, BF>& st, const char* rowp,
     }
 }
 
-template <int W, bool BF, int R, int WPS>
+// S0: a segment of n_out = 7 k7 - S0 output rows (any length >= 7) runs as a virtual segment of 7 k7 rows that starts S0 rows
+// higher and whose first S0 steps are not executed: the first and the last six executed steps then still sit at fixed phases of
+// the rotation, for every segment length (a multiple of 7 only would leave up to 12 % of the wave slots of stage 2 empty).
+template <int W, bool BF, int R, int WPS, int S0>
 __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __restrict__ x_, void* __restrict__ y_,
                                                              const float* __restrict__ wt /*[49][C]*/,
                                                              const float* __restrict__ bias, void* __restrict__ sink_,
@@ -262,8 +265,9 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
     // the three zero rows between clips; the last segment may reach past the last clip), input rows [vb - 3, ve + 3).  Step u
     // multiplies input row vb - 3 + u and completes output row vb - 6 + u; the 7 k7 + 6 steps run as groups of seven.
     const int Hp = H + 3;
-    const int n_out = 7 * k7;
+    const int n_out = 7 * k7 - S0;
     const int vb = seg * n_out;
+    const int vbv = vb - S0;                                        // first output row of the virtual segment
     const char* const x0 = reinterpret_cast<const char*>(x_);
     const char* pf_ptr;                                             // next in-image row at or after the prefetch cursor
     {
@@ -286,14 +290,14 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
     unsigned rmask = 0, omask = 0;
 #define ACX_DWC_FLAGS(g_)                                                                                       \
     {                                                                                                           \
-        const int u_ = 7 * (g_) - 3 + lane;                                                                     \
-        const int v_ = vb - 3 + u_;                                                                             \
-        const unsigned vv_ = (unsigned)(v_ + 9 * Hp);                 /* >= 0: v_ >= -9, Hp >= 4 */             \
+        const int u_ = 7 * (g_) - 3 + lane;                           /* virtual step */                        \
+        const int v_ = vbv - 3 + u_;                                                                            \
+        const unsigned vv_ = (unsigned)(v_ + 9 * Hp);                 /* >= 0: v_ >= -15, Hp >= 4 */            \
         const unsigned n_ = __umulhi(vv_, magic);                                                               \
         const unsigned r_ = vv_ - n_ * (unsigned)Hp;                                                            \
-        const bool real_ = v_ >= 0 && r_ < (unsigned)H && n_ < (unsigned)(B + 9) && u_ >= 0 && u_ < n_out + 6;  \
+        const bool real_ = v_ >= 0 && r_ < (unsigned)H && n_ < (unsigned)(B + 9) && u_ >= S0 && u_ < 7 * k7 + 6; \
         rmask = (unsigned)__ballot(real_);                                                                      \
-        omask = (unsigned)__ballot(real_ && u_ >= 3 && u_ < n_out + 3);                                         \
+        omask = (unsigned)__ballot(real_ && u_ >= S0 + 3 && u_ < 7 * k7 + 3);                                   \
     }
 
     // The out-of-image column slots of the ring are zeroed once and never written again (the three slots left and right of every
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
     }
     ACX_DWC_FLAGS(0)
 #pragma unroll
-    for (int i = 0; i < D; ++i) ACX_DWC_PREFETCH(i + 3, (unsigned)(i * Cfg::kRowB))
+    for (int i = 0; i < D; ++i) ACX_DWC_PREFETCH(S0 + i + 3, (unsigned)((R == 7 ? (S0 + i) % 7 : i) * Cfg::kRowB))
     ACX_DWC_STAMP(1)
     // ... and are first used here
 #pragma unroll
@@ -352,11 +356,19 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
             else *reinterpret_cast<dwc_f32x2*>(dst_ + p * C * kEsz) = st.acc[I_][p];                            \
         }                                                                                                       \
     }
-    // group 0: the first six input rows meet kernel rows 0 .. step only (the output rows above the segment are not this wave's)
-    ACX_DWC_STEP(0, 0, 0) ACX_DWC_STEP(1, 0, 1) ACX_DWC_STEP(2, 0, 2) ACX_DWC_STEP(3, 0, 3) ACX_DWC_STEP(4, 0, 4) ACX_DWC_STEP(5, 0, 5)
-    ACX_DWC_STEP(6, 0, 6)
+    // The first six executed steps (virtual steps S0 .. S0 + 5) meet kernel rows 0 .. step - S0 only (the output rows above the
+    // segment are not this wave's); they sit in group 0 and, for S0 >= 2, in the head of group 1.
+#define ACX_DWC_STEP_G0(I_) if constexpr ((I_) >= S0) ACX_DWC_STEP(I_, 0, ((I_) - S0 < 6 ? (I_) - S0 : 6))
+    ACX_DWC_STEP_G0(0) ACX_DWC_STEP_G0(1) ACX_DWC_STEP_G0(2) ACX_DWC_STEP_G0(3) ACX_DWC_STEP_G0(4) ACX_DWC_STEP_G0(5) ACX_DWC_STEP_G0(6)
+#undef ACX_DWC_STEP_G0
+    if constexpr (S0 >= 2) {
+        ACX_DWC_FLAGS(1)
+#define ACX_DWC_STEP_G1(I_) ACX_DWC_STEP(I_, 0, ((I_) + 7 - S0 < 6 ? (I_) + 7 - S0 : 6))
+        ACX_DWC_STEP_G1(0) ACX_DWC_STEP_G1(1) ACX_DWC_STEP_G1(2) ACX_DWC_STEP_G1(3) ACX_DWC_STEP_G1(4) ACX_DWC_STEP_G1(5) ACX_DWC_STEP_G1(6)
+#undef ACX_DWC_STEP_G1
+    }
     ACX_DWC_STAMP(3)
-    for (int g = 1; g < k7; ++g) {
+    for (int g = S0 >= 2 ? 2 : 1; g < k7; ++g) {
         ACX_DWC_FLAGS(g)
         ACX_DWC_STEP(0, 0, 6) ACX_DWC_STEP(1, 0, 6) ACX_DWC_STEP(2, 0, 6) ACX_DWC_STEP(3, 0, 6) ACX_DWC_STEP(4, 0, 6) ACX_DWC_STEP(5, 0, 6) ACX_DWC_STEP(6, 0, 6)
     }
@@ -375,6 +387,20 @@ __global__ __launch_bounds__(256, WPS) void dwconv7_col_kernel(const void* __res
 // target_waves: how many waves the launch should consist of (one per SIMD of the CUs it may use).  Every wave takes a
 // segment of 7 k output rows of the stacked batch (the rotation has seven phases: the first and the last six steps then sit at
 // fixed phases and are compiled with their reduced kernel-row ranges).
+template <int W, bool BF, int R, int WPS, int S0>
+static int launch_dw_col_s0(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H, int k7, int n_items, hipStream_t s) {
+    using Cfg = DwColCfg<W, BF, R>;
+    static DeviceOnce once;
+    ACX_TRY(set_max_dynamic_lds(once, &dwconv7_col_kernel<W, BF, R, WPS, S0>, Cfg::kLdsBytes));
+    launch_kernel(&dwconv7_col_kernel<W, BF, R, WPS, S0>, dim3((unsigned)((n_items + 3) / 4)), dim3(256), Cfg::kLdsBytes, s,
+        x, y, wt, bias, sink, B, H, k7, n_items, (unsigned)(0x100000000ull / (unsigned)(H + 3)) + 1u);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
+// target_waves: how many waves the launch should consist of (one per SIMD of the CUs it may use).  Every wave takes a segment
+// of n_out = ceil(rows / segments) output rows of the stacked batch; the kernel instantiation for n_out's remainder modulo the
+// rotation's seven phases (S0) runs it.
 template <int W, bool BF, int R, int WPS>
 static int launch_dw_col_cfg(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H,
                              int target_waves, hipStream_t s) {
@@ -385,17 +411,22 @@ static int launch_dw_col_cfg(const void* x, void* y, const float* wt, const floa
         ACX_FAIL(ACX_ERR_SHAPE, "dwconv7: batch too tall for one launch (%d clips of %d rows)", B, H);
     long long segs = (long long)target_waves * WPS / Cfg::kUnits;
     if (segs < 1) segs = 1;
-    long long k7 = (Vt + 7 * segs - 1) / (7 * segs);                   // ceil(rows per segment / 7)
-    const long long kmin = WPS == 2 ? 1 : (kDwColMinRows + 6) / 7;
-    if (k7 < kmin) k7 = kmin;
-    const long long n_seg = (Vt + 7 * k7 - 1) / (7 * k7);
+    long long n_out = (Vt + segs - 1) / segs;                          // output rows per segment
+    const long long nmin = WPS == 2 ? 7 : kDwColMinRows;
+    if (n_out < nmin) n_out = nmin;
+    const int s0 = (int)((7 - n_out % 7) % 7);
+    const int k7 = (int)((n_out + s0) / 7);
+    const long long n_seg = (Vt + n_out - 1) / n_out;
     const int n_items = (int)(n_seg * Cfg::kUnits);
-    static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &dwconv7_col_kernel<W, BF, R, WPS>, Cfg::kLdsBytes));
-    launch_kernel(&dwconv7_col_kernel<W, BF, R, WPS>, dim3((unsigned)((n_items + 3) / 4)), dim3(256), Cfg::kLdsBytes, s,
-        x, y, wt, bias, sink, B, H, (int)k7, n_items, (unsigned)(0x100000000ull / (unsigned)(H + 3)) + 1u);
-    ACX_HIP(hipGetLastError());
-    return ACX_OK;
+    switch (s0) {
+        case 0: return launch_dw_col_s0<W, BF, R, WPS, 0>(x, y, wt, bias, sink, B, H, k7, n_items, s);
+        case 1: return launch_dw_col_s0<W, BF, R, WPS, 1>(x, y, wt, bias, sink, B, H, k7, n_items, s);
+        case 2: return launch_dw_col_s0<W, BF, R, WPS, 2>(x, y, wt, bias, sink, B, H, k7, n_items, s);
+        case 3: return launch_dw_col_s0<W, BF, R, WPS, 3>(x, y, wt, bias, sink, B, H, k7, n_items, s);
+        case 4: return launch_dw_col_s0<W, BF, R, WPS, 4>(x, y, wt, bias, sink, B, H, k7, n_items, s);
+        case 5: return launch_dw_col_s0<W, BF, R, WPS, 5>(x, y, wt, bias, sink, B, H, k7, n_items, s);
+        default: return launch_dw_col_s0<W, BF, R, WPS, 6>(x, y, wt, bias, sink, B, H, k7, n_items, s);
+    }
 }
 
 // Occupancy by stage: the HBM-bound stages 0-1 in fp32 run one wave per SIMD (long segments: few halo rows, a deep ring);
