@@ -16,14 +16,14 @@ variant() {   # name, sed expressions...
 variant full
 EXTRA=-DACX_FW_STAMPS variant stamps
 variant nogelu 's/^(\s+)ACX_FENCE if constexpr \(HV_\) \{ ACX_NANO_RANGE.*$/\1ACX_FENCE/'
-variant nodma 's/^        acx_glds16_own_m0\(wstream/        if (0) acx_glds16_own_m0(wstream/'
+variant nodma 's/acx_glds16_run\(wbase, \(piece_\) % 8\);//'
 variant nobarrier 's/^        __builtin_amdgcn_s_barrier\(\);  /  /'
 variant nodsread 's/^#define ACX_W1_RD\(base_, u_, pl_\).*/#define ACX_W1_RD(base_, u_, pl_) (acth[0][(u_) % 4])/; s/^#define ACX_W2_RD\(base_, i_, pl_\).*/#define ACX_W2_RD(base_, i_, pl_) (actl[0][(i_) % 4])/'
 variant nomfma 's/^#define ACX_M16\(a_, b_, c_\).*/#define ACX_M16(a_, b_, c_) asm volatile("" :: "v"(a_), "v"(b_));/'
 EXTRA=-DACX_FW_STAMPS variant stamps_nomfma 's/^#define ACX_M16\(a_, b_, c_\).*/#define ACX_M16(a_, b_, c_) asm volatile("" :: "v"(a_), "v"(b_));/'
 NOGELU='s/^(\s+)ACX_FENCE if constexpr \(HV_\) \{ ACX_NANO_RANGE.*$/\1ACX_FENCE/; s/^        if constexpr \(HV\) \{ ACX_NANO_RANGE\([01], 0, Cfg::kNanoHead\) \}$/ /'
 NODS='s/^#define ACX_W1_RD\(base_, u_, pl_\).*/#define ACX_W1_RD(base_, u_, pl_) (acth[0][(u_) % 4])/; s/^#define ACX_W2_RD\(base_, i_, pl_\).*/#define ACX_W2_RD(base_, i_, pl_) (actl[0][(i_) % 4])/'
-NODMA='s/^        acx_glds16_own_m0\(wstream/        if (0) acx_glds16_own_m0(wstream/'
+NODMA='s/acx_glds16_run\(wbase, \(piece_\) % 8\);//'
 EXTRA=-DACX_FW_STAMPS variant st_nogelu "$NOGELU"
 EXTRA=-DACX_FW_STAMPS variant st_nodsread "$NODS"
 EXTRA=-DACX_FW_STAMPS variant st_nodma "$NODMA"

@@ -12,6 +12,9 @@ namespace acx {
 void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 ProfScope::ProfScope(acx_ctx*, int, hipStream_t) : ctx(nullptr) {}
 ProfScope::~ProfScope() {}
+void prof_next_events(hipEvent_t* a, hipEvent_t* b) { *a = nullptr; *b = nullptr; }
+thread_local int tls_inflight_ways = 1;
+Tuning& tuning() { static Tuning t; return t; }
 }
 
 int main(int argc, char** argv) {
