@@ -227,6 +227,7 @@ struct Tuning {
     std::atomic<int> wide_npb{0};      // ACX_WIDE_NPB = 1 | 2: pixel blocks per wave of the wide fused MLP (0: by launch size)
     std::atomic<int> gemm_32x32{0};    // ACX_GEMM_32X32 = 1: the 32x32x16 form of the split GEMM
     std::atomic<int> fail_sub{-1};     // ACX_TEST_FAIL_SUB = i: acx_forward reports a failure after queueing sub-batch i (error-path tests)
+    std::atomic<int> wide_pers{0};     // ACX_WIDE_PERSIST: 1 = persistent wide fused MLP wherever it exists, 2 = never; 0 = by launch size
     std::atomic<int> dw_stream{-1};    // ACX_DW_STREAM = 0 | 1: forces the tile / column-streaming depthwise kernels (-1: by launch size)
 };
 Tuning& tuning();

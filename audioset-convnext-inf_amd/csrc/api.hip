@@ -25,6 +25,7 @@ void tuning_reload() {
     Tuning& t = tuning();
     t.gemm_mi.store(digit("ACX_GEMM_MI", "124", 0), std::memory_order_relaxed);
     t.wide_npb.store(digit("ACX_WIDE_NPB", "12", 0), std::memory_order_relaxed);
+    t.wide_pers.store(digit("ACX_WIDE_PERSIST", "01", -1) < 0 ? 0 : (digit("ACX_WIDE_PERSIST", "01", 0) == 1 ? 1 : 2), std::memory_order_relaxed);
     t.gemm_32x32.store(digit("ACX_GEMM_32X32", "1", 0), std::memory_order_relaxed);
     t.dw_stream.store(digit("ACX_DW_STREAM", "01", -1), std::memory_order_relaxed);
     t.fail_sub.store(digit("ACX_TEST_FAIL_SUB", "0123", -1), std::memory_order_relaxed);

@@ -340,11 +340,14 @@ __global__ __launch_bounds__(256 + 64 * DW) void gemm_f32_kernel(GemmParams p) {
                 else v[r] += bn;
             }
             if (full) {
+                // (round 4: all sixteen residual values requested before the first store -- out may alias resid, so hipcc kept
+                // every load behind the previous store and waited for both: 16 dependent L2 round trips per 32 x 32 block)
+                if (EPI == EPI_RESID) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long off = (long long)((r & 3) + 8 * (r >> 2)) * p.N;
-                    op[off] = (EPI == EPI_RESID) ? v[r] + rp[off] : v[r];
+                    for (int r = 0; r < 16; ++r) v[r] += rp[(long long)((r & 3) + 8 * (r >> 2)) * p.N];
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) op[(long long)((r & 3) + 8 * (r >> 2)) * p.N] = v[r];
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

@@ -9,6 +9,8 @@
 // fragment read is still one ds_read_b128: lane half h takes chunk 2g+h of its row = k 16g+8h .. +7, exactly
 // the A/B lane map of the 32x32x16 instruction, so one MFMA per (tile, k-group) replaces four fp32 ones.
 #include <cstdlib>
+#include <type_traits>
+
 #include "acx_internal.h"
 #include "split_math.h"
 
@@ -200,32 +202,56 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
 #undef ACX_TOUCH
 
     // ---- epilogue: D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ---------------------
-    const bool full = m0 + kBM <= p.M;
+    // Round 4: a tile inside M runs without per-element masks, its biases are loaded once and the residual values of a 32-row
+    // block are all requested before the block's first store.  Before, every element of EPI 2 was a load, a wait for ALL
+    // outstanding vector-memory operations (the previous store included) and a store: 96 dependent L2 round trips per thread and
+    // tile with nothing else on the CU-exclusive workgroup's CU to hide them (tools/lab/isa_skeleton.py).
+    float bnj[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const long long mb = m0 + (wm * TM + i) * 32 + 4 * hh;
+    for (int j = 0; j < TN; ++j) bnj[j] = p.bias[n0 + (wn * TN + j) * 32 + l31];
+    auto epilogue = [&](auto masked) __attribute__((always_inline)) {
+        constexpr bool kMasked = decltype(masked)::value;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + l31;
-            const float bn = p.bias[n];
+        for (int i = 0; i < TM; ++i) {
+            const long long mb = m0 + (wm * TM + i) * 32 + 4 * hh;
+            float rv[TN][16];
+            if (EPI == 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = (r & 3) + 8 * (r >> 2);
-                if (full || mb + dr < p.M) {
-                    const long long off = (mb + dr) * p.N + n;
-                    float v = acc[i][j][r] + bn;
-                    if (EPI == 1) {
-                        reinterpret_cast<__bf16*>(p.out)[off] = (__bf16)gelu_erf_b(v);
-                    } else if (EPI == 3) {
-                        reinterpret_cast<__bf16*>(p.out)[off] = (__bf16)v;
-                    } else {
-                        if (EPI == 2) v += p.resid[off];
-                        reinterpret_cast<float*>(p.out)[off] = v;
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + (wn * TN + j) * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        const long long mr = (!kMasked || mb + dr < p.M) ? mb + dr : p.M - 1;     // (clamped: the value is not used)
+                        rv[j][r] = p.resid[mr * p.N + n];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + l31;
+                const float bn = bnj[j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (!kMasked || mb + dr < p.M) {
+                        const long long off = (mb + dr) * p.N + n;
+                        float v = acc[i][j][r] + bn;
+                        if (EPI == 1) {
+                            reinterpret_cast<__bf16*>(p.out)[off] = (__bf16)gelu_erf_b(v);
+                        } else if (EPI == 3) {
+                            reinterpret_cast<__bf16*>(p.out)[off] = (__bf16)v;
+                        } else {
+                            if (EPI == 2) v += rv[j][r];
+                            reinterpret_cast<float*>(p.out)[off] = v;
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    if (m0 + kBM <= p.M) epilogue(std::false_type{});
+    else epilogue(std::true_type{});
 }
 
 template <int kBM, int BN, int WM, int WN, int EPI, int GATHER>

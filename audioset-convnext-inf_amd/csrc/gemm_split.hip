@@ -25,6 +25,8 @@
 // the pipeline is deeper than the fp32 kernel's: B tile t+2 and A tiles t+2, t+3 are in flight while tile t is multiplied.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "acx_internal.h"
 #include "split_math.h"
 
@@ -257,6 +259,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
 #undef ACX_H8
 
     const float sinv = p.sinv;
+    f32x4 bjq[TN][4];             // (round 4: biases loaded once, not once per store -- see gemm_split16_kernel's epilogue)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bjq[j][q] = *reinterpret_cast<const f32x4*>(p.bias + n0 + (wn * TN + j) * 32 + 8 * q + 4 * hh);
     if (EPI == 1) {
         const GeluK3 gk = gelu_k3(sinv, p.hscale);      // GELU of v = a * sinv, result x p.hscale (split_math.h, third form)
         const float binv = 1.0f / sinv;     // a power of two
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
                 const int nb = n0 + (wn * TN + j) * 32;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * q + 4 * hh);
+                    const f32x4 b4 = bjq[j][q];
                     unsigned xh[2], xl[2];
 #pragma unroll
                     for (int e2 = 0; e2 < 2; ++e2) {      // acc holds v / sinv - bias / sinv: add the pre-scaled bias first
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmSParams p)
                 const int nb = n0 + (wn * TN + j) * 32;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * q + 4 * hh);
+                    const f32x4 b4 = bjq[j][q];
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -540,7 +547,16 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
 #undef ACX_H8
 
     // ---- epilogues: lane (l15, g4) owns row m = m0 + 64 wm + 16 i + l15, columns nb + 4 g4 .. + 3 of block (i, j) ------
+    // Round 4: the bias vectors are loaded ONCE, ahead of the loops, and a tile that lies inside M stores without a mask.  Before,
+    // every (i, j) step loaded its bias again and stored behind `if (ok)`: a load, a wait and a store per step, each in a basic
+    // block of its own, where hipcc can only wait for ALL outstanding vector-memory operations -- the previous store included:
+    // 24 dependent L2 round trips per thread and tile with nothing else on the CU to hide them (tools/lab/isa_skeleton.py).
     const float sinv = p.sinv;
+    f32x4 bj[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 96 + j * 16 + 4 * g4);
+    auto epilogue = [&](auto masked) __attribute__((always_inline)) {
+    constexpr bool kMasked = decltype(masked)::value;
     if (EPI == 1) {
         const GeluK3 gk = gelu_k3(sinv, p.hscale);      // GELU of v = a * sinv, result x p.hscale (split_math.h, third form)
         const float binv = 1.0f / sinv;     // a power of two
@@ -550,12 +566,12 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const long long m = m0 + wm * (16 * MI) + i * 16 + l15;
-            const bool ok = m < p.M;
+            const bool ok = !kMasked || m < p.M;
             char* orow = outb + (ok ? m : 0) * p.N * 4;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int nb = n0 + wn * 96 + j * 16;
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * g4);
+                const f32x4 b4 = bj[j];
                 unsigned xh[2], xl[2];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {      // acc holds v / sinv - bias / sinv: add the pre-scaled bias first
@@ -573,30 +589,38 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmSParams p) {
         }
     } else {
         float* outf = reinterpret_cast<float*>(p.out);
+        // EPI 2: the residual values of row block i + 1 are requested before row block i is stored (two register sets)
+        f32x4 rv[2][NJ];
+        auto load_resid = [&](const int i) __attribute__((always_inline)) {
+            const long long m = m0 + wm * (16 * MI) + i * 16 + l15;
+            const long long row = ((!kMasked || m < p.M) ? m : 0) * p.N;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rv[i & 1][j] = *reinterpret_cast<const f32x4*>(p.resid + row + n0 + wn * 96 + j * 16 + 4 * g4);
+        };
+        if (EPI == 2) load_resid(0);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const long long m = m0 + wm * (16 * MI) + i * 16 + l15;
-            const bool ok = m < p.M;
+            const bool ok = !kMasked || m < p.M;
             const long long row = (ok ? m : 0) * p.N;
-            f32x4 rv[NJ];
-            if (EPI == 2) {       // all residual loads of the row in flight before the first store
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) rv[j] = *reinterpret_cast<const f32x4*>(p.resid + row + n0 + wn * 96 + j * 16 + 4 * g4);
-            }
+            if (EPI == 2 && i + 1 < MI) load_resid(i + 1);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int nb = n0 + wn * 96 + j * 16;
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * g4);
+                const f32x4 b4 = bj[j];
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = fmaf(acc[i][j][e], sinv, b4[e]);
-                    if (EPI == 2) v[e] += rv[j][e];
+                    if (EPI == 2) v[e] += rv[i & 1][j][e];
                 }
                 if (ok) *reinterpret_cast<f32x4*>(outf + row + nb + 4 * g4) = v;
             }
         }
     }
+    };
+    if (m0 + 64 * MI <= p.M) epilogue(std::false_type{});
+    else epilogue(std::true_type{});
 }
 
 template <int EPI, int GATHER, int MI>

@@ -76,7 +76,7 @@ struct WideCfg {
     static constexpr int kPieces = kSegBytes / 1024 / kWaves;   // 1-KB LDS-DMA pieces per wave per segment
     static constexpr int kSteps = C / 16;                   // units of a phase-1 segment (k-steps)
     static constexpr int kUnits = 2 * (C / 32);             // units of a phase-2 segment (out tile, k-step)
-    static constexpr size_t kLdsBytes = 3 * (size_t)kSegBytes + 4 * C * 4;
+    static constexpr size_t kLdsBytes = 3 * (size_t)kSegBytes + 4 * C * 4 + C * 4;      // ring, b1 (pre-divided), b2
     static constexpr int kMfmas = 3 * kUnits * PT;          // MFMAs per segment
     static constexpr int kDmaStride = kUnits / kPieces;     // one LDS-DMA piece every kDmaStride units
     // GELU nano-steps (single instructions, split_math.h) a segment carries: half of a pixel tile's 8 register pairs
@@ -114,7 +114,15 @@ struct WideCfg {
 //   W1(k): k == 0 ? 0 : 2k - 1       W2(k): k == n - 1 ? 2n - 1 : 2k + 2
 // NPB = 16-pixel blocks per wave: 2 (a 128-pixel tile per workgroup), or 1 for launches whose 64-pixel tiles all find a CU at
 // once (small batches: twice the workgroups, ~0.65 of the time each; the arithmetic of a pixel is the same in both)
-template <int C, int PT, bool LNOUT, int NPB>
+// PERS (round 4, C = 192): ONE workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...  A CU-exclusive workgroup cannot hide
+// its own HBM round trips behind a neighbour's arithmetic, and with every CU starting its tile at the same moment the y-row
+// loads of the prologue and the stores of the epilogue arrive at the memory system as two bursts per round (tools/lab:
+// prologue 14 k + epilogue 11 k of a tile's 111 k cycles at C = 192, profiles/r04_k_wide192_ablation.txt).  The persistent
+// form requests the NEXT tile's y rows into registers the C = 192 kernel has to spare (96 per lane) during segment 2n - 5, lets
+// the weight ring run on across the tile boundary (segments 0 and 1 of the next tile are requested during the last two), and
+// leaves the stores of a tile in flight under the LayerNorm and the first segment of the next one.  C = 384 has no registers
+// left for the rows and keeps the one-tile form.
+template <int C, int PT, bool LNOUT, int NPB, bool PERS>
 __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     const float* __restrict__ y, float* __restrict__ x, const char* __restrict__ wstream /*[2n][128 C bytes]*/,
     const float* __restrict__ b1, const float* __restrict__ b2, long long M, float sinv1, float sinv2, float hscale,
@@ -122,6 +130,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     using Cfg = WideCfg<C, PT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* b1s = reinterpret_cast<float*>(smem + 3 * Cfg::kSegBytes);   // [4C], pre-divided by sinv1
+    float* b2s = b1s + 4 * C;                                           // [C]: read by the epilogue (as loads from b2 in its
+    // loop they were one L2 round trip per 16 channels -- hipcc waits vmcnt(0) for each, i.e. for the previous store as well)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -134,12 +144,17 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     ACX_WSTAMP(-1)
     long long mrow[2];            // this lane's pixel row in each of the wave's two 16-pixel blocks
     bool valid[2];
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-        mrow[pb] = (long long)blockIdx.x * (Cfg::kWaves * 16 * NPB) + wave * (16 * NPB) + (pb < NPB ? pb : 0) * 16 + l15;
-        valid[pb] = pb < NPB && mrow[pb] < M;
-        if (mrow[pb] >= M) mrow[pb] = M - 1;
+    static_assert(!PERS || NPB == 2, "the persistent form is written for 128-pixel tiles");
+    constexpr int kPixT = Cfg::kWaves * 16 * NPB;
+    const long long n_tiles = (M + kPixT - 1) / kPixT;
+    long long tile = blockIdx.x;
+#define ACX_TILE_ROWS(t_)                                                                                       \
+    _Pragma("unroll") for (int pb = 0; pb < 2; ++pb) {                                                          \
+        mrow[pb] = (t_) * kPixT + wave * (16 * NPB) + (pb < NPB ? pb : 0) * 16 + l15;                           \
+        valid[pb] = pb < NPB && mrow[pb] < M;                                                                   \
+        if (mrow[pb] >= M) mrow[pb] = M - 1;                                                                    \
     }
+    ACX_TILE_ROWS(tile)
 
     constexpr int n = Cfg::kChunks;
     const int dma_lane = (wave * Cfg::kPieces) * 1024 + lane * 16;      // this lane's slot in piece 0 of its wave
@@ -169,18 +184,63 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         const int i = q * Cfg::kThreads + tid;
         b1v[q] = reinterpret_cast<const float4*>(b1)[i < C ? i : 0];
     }
+    const float4 b2v = reinterpret_cast<const float4*>(b2)[tid < C / 4 ? tid : 0];
 
     // ---- this wave's activations: lane (px = l15 of block pb, k block g4) holds channels 32 s + 8 g4 .. + 7, s = 0..C/32-1 ----
     constexpr int kS32 = C / 32;
     f32x4 acth[2][kS32], actl[2][kS32];                         // 8 fp16 halves each
+    // PERS: the rows of a tile are requested one tile ahead, through a pointer the compiler knows nothing about (as loads of a
+    // const __restrict__ argument they could be moved anywhere, e.g. down to their first use); the counted waits of the
+    // segments around the request allow for exactly kAhead further vector-memory instructions in flight (ACX_SEG_END)
+    constexpr int kAhead = 2 * (C / 16);                        // loads of the next tile's y rows = loads of x = stores of x
+    typedef const float __attribute__((address_space(1))) * GlobalF;       // (laundered pointers lose the inferred address space)
+    typedef const f32x4 __attribute__((address_space(1))) * GlobalF4;
+    GlobalF yl = (GlobalF)y;
+    if constexpr (PERS) asm volatile("" : "+s"(yl));
+    f32x4 yraw[PERS ? 2 : 1][PERS ? 2 * kS32 : 1];
+    long long mrow_n[2];
+#define ACX_Y_LOAD(rows_)                                                                                       \
+    _Pragma("unroll") for (int pb = 0; pb < 2; ++pb) {                                                          \
+        GlobalF yp = yl + (rows_)[pb] * C + 8 * g4;                                                             \
+        _Pragma("unroll") for (int s = 0; s < kS32; ++s) {                                                      \
+            yraw[pb][2 * s] = *(GlobalF4)(yp + 32 * s);                                                         \
+            yraw[pb][2 * s + 1] = *(GlobalF4)(yp + 32 * s + 4);                                                 \
+        }                                                                                                       \
+    }
+    // bias staging: 16 bytes per lane into the LDS (the loads were requested ahead of the tile's rows: vmcnt completes in order)
+#define ACX_BIAS_STAGE()                                                                                        \
+    {                                                                                                           \
+        const float b1scale = 1.0f / sinv1;             /* a power of two */                                    \
+        _Pragma("unroll") for (int q = 0; q < kB1Iters; ++q) {                                                  \
+            const int i = q * Cfg::kThreads + tid;                                                              \
+            float4 v = b1v[q];                                                                                  \
+            v.x *= b1scale; v.y *= b1scale; v.z *= b1scale; v.w *= b1scale;                                     \
+            if (i < C) reinterpret_cast<float4*>(b1s)[i] = v;                                                   \
+        }                                                                                                       \
+        static_assert(C / 4 <= Cfg::kThreads, "one float4 of b2 per thread");                                   \
+        if (tid < C / 4) reinterpret_cast<float4*>(b2s)[tid] = b2v;                                             \
+    }
+    if constexpr (PERS) { ACX_Y_LOAD(mrow) ACX_BIAS_STAGE() }
+    bool first = true;
+    for (;;) {                                                  // PERS: tiles blockIdx.x, + gridDim.x, ...; else one pass
+    const bool has_next = PERS && tile + gridDim.x < n_tiles;
+    if constexpr (PERS) {
+        const long long tn = has_next ? tile + gridDim.x : tile;     // (no successor: the rows are requested all the same -- the waits count them)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            mrow_n[pb] = tn * kPixT + wave * (16 * NPB) + pb * 16 + l15;
+            if (mrow_n[pb] >= M) mrow_n[pb] = M - 1;
+        }
+    }
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
         float a[C / 4];
         const float* yp = y + mrow[pb] * C + 8 * g4;
 #pragma unroll
         for (int s = 0; s < kS32; ++s) {
-            const float4 v0 = *reinterpret_cast<const float4*>(yp + 32 * s);
-            const float4 v1 = *reinterpret_cast<const float4*>(yp + 32 * s + 4);
+            f32x4 v0, v1;
+            if constexpr (PERS) { v0 = yraw[pb][2 * s]; v1 = yraw[pb][2 * s + 1]; }
+            else { v0 = *reinterpret_cast<const f32x4*>(yp + 32 * s); v1 = *reinterpret_cast<const f32x4*>(yp + 32 * s + 4); }
             a[8 * s + 0] = v0.x; a[8 * s + 1] = v0.y; a[8 * s + 2] = v0.z; a[8 * s + 3] = v0.w;
             a[8 * s + 4] = v1.x; a[8 * s + 5] = v1.y; a[8 * s + 6] = v1.z; a[8 * s + 7] = v1.w;
         }
@@ -208,16 +268,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         }
     }
 
-    {
-        const float b1scale = 1.0f / sinv1;             // a power of two
-#pragma unroll
-        for (int q = 0; q < kB1Iters; ++q) {
-            const int i = q * Cfg::kThreads + tid;
-            float4 v = b1v[q];
-            v.x *= b1scale; v.y *= b1scale; v.z *= b1scale; v.w *= b1scale;
-            if (i < C) reinterpret_cast<float4*>(b1s)[i] = v;
-        }
-    }
+    if constexpr (!PERS) { ACX_BIAS_STAGE() }     // behind the rows, so that it has no wait of its own
     f32x4 acc[C / 16][2];         // out^T: block cb = 16 out channels x pixel block pb; lane holds channels 16 cb + 4 g4 .. + 3
 #pragma unroll
     for (int cb = 0; cb < C / 16; ++cb)
@@ -297,10 +348,12 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             gl[pb_] = __builtin_bit_cast(f32x4, uint4{ul[0][4 * pb_ + 0], ul[0][4 * pb_ + 1], ul[0][4 * pb_ + 2], ul[0][4 * pb_ + 3]}); }
     // end of a segment: the pieces requested during it may stay in flight, everything older must have landed, and
     // every wave must be done reading the segment before its ring slot is requested again
-#define ACX_SEG_END(issued_, stamp_)                                                                            \
+    // (extra_: PERS -- kAhead loads or stores issued since the pieces of the PREVIOUS segment may stay in flight as well; they
+    // are younger than those pieces, and vector-memory operations complete in order)
+#define ACX_SEG_END(issued_, stamp_, extra_)                                                                    \
         ACX_FENCE                                                                                               \
         ACX_WSTAMP(stamp_)                                                                                      \
-        if (issued_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::kPieces) : "memory");                       \
+        if (issued_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::kPieces + (extra_)) : "memory");            \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
         __builtin_amdgcn_s_barrier();                                                                           \
         ACX_FENCE                                                                                               \
@@ -312,12 +365,15 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     GeluState3 gsv[2];
 
     // one phase-1 segment: X = b1 + W1c . LN(y)^T for chunk k_, image in ring slot grp_, requesting segment seg_ + 2
-    auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
+    // opt (PERS): bit 0 = the segment-end wait leaves kAhead further operations in flight; bit 1 = request the next tile's rows
+    auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_, auto opt) __attribute__((always_inline)) {
+        constexpr int kOpt = decltype(opt)::value;
         // second half of the GELU of Xv (the pairs of pixel block 1) rides on this segment's MFMAs
         constexpr bool HV = decltype(with_gelu)::value && NPB == 2;
         constexpr bool kPack = decltype(with_gelu)::value;
         const char* base = smem + grp_ * Cfg::kSegBytes;
-        const bool dma = seg_ + 2 < Cfg::kSegs;
+        const bool dma = seg_ + 2 < Cfg::kSegs || has_next;
+        const int dseg = seg_ + 2 < Cfg::kSegs ? seg_ + 2 : seg_ + 2 - Cfg::kSegs;      // the ring runs on into the next tile
         const int g2 = (grp_ + 2) % 3;
         ACX_BIAS_INIT(k_)
         // fragments are read TWO units ahead of their MFMAs (three register sets rotating): with one unit of look-ahead
@@ -334,7 +390,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #define ACX_P1_UNIT(u_, ch_, cl_, th_, tl_)                                                                     \
             ACX_FENCE                                                                                           \
             ACX_M16(cl_, acth[0][(u_) >> 1], Xn[(u_) & 1])                                                      \
-            if ((u_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (u_) / Cfg::kDmaStride, g2) }          \
+            if ((u_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(dseg, (u_) / Cfg::kDmaStride, g2) }              \
             ACX_NANO_AT(HV, 1, 6 * (u_) + 0)                                                                    \
             if constexpr (NPB == 2) { ACX_M16(cl_, acth[1][(u_) >> 1], Xn[2 + ((u_) & 1)]) }                        \
             if ((u_) + 3 < Cfg::kSteps) cl_ = ACX_W1_RD(base, (u_) + 3, 1);                                     \
@@ -360,14 +416,17 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         if constexpr (kPack) { ACX_PACK_G() }
 #pragma unroll
         for (int q = 0; q < 4; ++q) Xv[q] = Xn[q];
-        ACX_SEG_END(dma, 1)
+        if constexpr ((kOpt & 2) != 0) { ACX_FENCE ACX_Y_LOAD(mrow_n) }
+        ACX_SEG_END(dma, 1, (kOpt & 1) ? kAhead : 0)
     };
     // one phase-2 segment: out^T += W2c . G for the chunk whose G sits in gh / gl, image in ring slot grp_; with_gelu:
     // the first half of the GELU + split of Xv (the NEXT chunk) rides on this segment's MFMAs
-    auto phase2 = [&](auto with_gelu, const int seg_, const int grp_) __attribute__((always_inline)) {
+    auto phase2 = [&](auto with_gelu, const int seg_, const int grp_, auto opt) __attribute__((always_inline)) {
         constexpr bool HV = decltype(with_gelu)::value;
+        constexpr int kOpt = decltype(opt)::value;
         const char* base = smem + grp_ * Cfg::kSegBytes;
-        const bool dma = seg_ + 2 < Cfg::kSegs;
+        const bool dma = seg_ + 2 < Cfg::kSegs || has_next;
+        const int dseg = seg_ + 2 < Cfg::kSegs ? seg_ + 2 : seg_ + 2 - Cfg::kSegs;
         const int g2 = (grp_ + 2) % 3;
         static_assert(Cfg::kUnits % 3 == 0, "the unit loop is unrolled by three");
         f32x4 f0h = ACX_W2_RD(base, 0, 0), f0l = ACX_W2_RD(base, 0, 1), f1h = ACX_W2_RD(base, 1, 0), f1l = ACX_W2_RD(base, 1, 1),
@@ -378,7 +437,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #define ACX_P2_UNIT(i_, ch_, cl_, th_, tl_)                                                                     \
             ACX_FENCE                                                                                           \
             ACX_M16(cl_, gh[0], acc[i_][0])                                                                     \
-            if ((i_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, (i_) / Cfg::kDmaStride, g2) }          \
+            if ((i_) % Cfg::kDmaStride == 0 && dma) { ACX_WDMA(dseg, (i_) / Cfg::kDmaStride, g2) }              \
             ACX_NANO_AT(HV, 0, 6 * (i_) + 0)                                                                    \
             if constexpr (NPB == 2) { ACX_M16(cl_, gh[1], acc[i_][1]) }                                         \
             if ((i_) + 3 < Cfg::kUnits) cl_ = ACX_W2_RD(base, (i_) + 3, 1);                                     \
@@ -401,32 +460,48 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
             ACX_P2_UNIT(i + 2, f2h, f2l, f0h, f0l)
         }
 #undef ACX_P2_UNIT
-        ACX_SEG_END(dma, 2)
+        ACX_SEG_END(dma, 2, (kOpt & 1) ? kAhead : 0)
     };
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // segments 0 and 1 landed ...
-    __syncthreads();                                      // ... for every wave; b1s visible
+    using Opt0 = std::integral_constant<int, 0>;
+    using OptA = std::integral_constant<int, PERS ? 1 : 0>;       // kAhead more in flight at the segment's end
+    using OptY = std::integral_constant<int, PERS ? 3 : 0>;       // the same + request the next tile's rows
+    static_assert(!PERS || (Cfg::kSegs % 3 == 0 && n >= 4 && Cfg::kPieces + kAhead < 64), "ring phase at a tile boundary; vmcnt is 6 bits");
+    if (first) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // segments 0 and 1 landed ...
+        __syncthreads();                                  // ... for every wave; b1s visible
+    }
+    // (PERS, later tiles: segment 0 landed behind the barrier of the previous tile's last segment, segment 1 lands by the end of
+    // this tile's segment 0, whose wait leaves the previous tile's stores in flight)
     ACX_WSTAMP(0)                                         // tile prologue: y rows, LayerNorm, first two segments' flight
     // segment 0: phase 1 of chunk 0; the first half of its GELU has nothing to ride on
-    phase1(std::false_type{}, 0, 0, 0);
+    phase1(std::false_type{}, 0, 0, 0, OptA{});
     ACX_NANO_RANGE(0, 0, Cfg::kNano)
     // segments 2k-1 (phase 1 of chunk k + second half of GELU(k-1)) and 2k (phase 2 of chunk k-1 + first half of GELU(k));
     // ring slot = segment % 3
     int grp = 1;
-    for (int k = 1; k < n - 1; ++k) {
-        phase1(std::true_type{}, k, 2 * k - 1, grp);
+    for (int k = 1; k < (PERS ? n - 2 : n - 1); ++k) {
+        phase1(std::true_type{}, k, 2 * k - 1, grp, Opt0{});
         grp = grp == 2 ? 0 : grp + 1;
-        phase2(std::true_type{}, 2 * k, grp);
+        phase2(std::true_type{}, 2 * k, grp, Opt0{});
         grp = grp == 2 ? 0 : grp + 1;
     }
-    phase1(std::true_type{}, n - 1, 2 * n - 3, grp);
+    if constexpr (PERS) {
+        // the next tile's rows are requested at the end of segment 2n - 5, behind its last piece; they must have landed by the end
+        // of segment 2n - 3 (the pieces requested during 2n - 4 are younger): two segments, ~2 us
+        phase1(std::true_type{}, n - 2, 2 * n - 5, grp, OptY{});
+        grp = grp == 2 ? 0 : grp + 1;
+        phase2(std::true_type{}, 2 * n - 4, grp, OptA{});
+        grp = grp == 2 ? 0 : grp + 1;
+    }
+    phase1(std::true_type{}, n - 1, 2 * n - 3, grp, Opt0{});
     grp = grp == 2 ? 0 : grp + 1;
     // the activations are dead from here on: their registers take the residual x of the tile, requested two segments
     // (~2 us) before the epilogue needs it
     // (C = 384: all but the last kLateX blocks per pixel block -- with all 48 in flight hipcc spilled three of them, each spill a
     // load + s_waitcnt vmcnt(0) + scratch store, i.e. three serial HBM round trips in the middle of the tile; the late ones are
     // requested at the top of the epilogue, into registers the loop has freed by then)
-    constexpr int kLateX = C >= 384 ? 2 : 0;
+    constexpr int kLateX = C >= 384 ? 3 : 0;
     constexpr int kEarlyX = C / 16 - kLateX;
     f32x4 xr[2][kEarlyX];
 #pragma unroll
@@ -435,12 +510,12 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #pragma unroll
         for (int cb = 0; cb < kEarlyX; ++cb) xr[pb][cb] = *reinterpret_cast<const f32x4*>(xp + 16 * cb);
     }
-    phase2(std::true_type{}, 2 * n - 2, grp);
+    static_assert(!PERS || 2 * kEarlyX == kAhead, "the wait of segment 2n - 2 counts the x loads");
+    phase2(std::true_type{}, 2 * n - 2, grp, OptA{});
     grp = grp == 2 ? 0 : grp + 1;
     if constexpr (NPB == 2) { ACX_NANO_RANGE(1, 0, Cfg::kNano) }      // second half of the last chunk's GELU: no phase-1 segment left to ride on
     ACX_PACK_G()
-    phase2(std::false_type{}, 2 * n - 1, grp);
-#undef ACX_WDMA
+    phase2(std::false_type{}, 2 * n - 1, grp, Opt0{});
 #undef ACX_H8
 #undef ACX_FENCE
 #undef ACX_W1_RD
@@ -461,6 +536,11 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
 #pragma unroll
         for (int i = 0; i < kLateX; ++i) xl[pb][i] = *reinterpret_cast<const f32x4*>(x + mrow[pb] * C + 4 * g4 + 16 * (kEarlyX + i));
 #define ACX_XR(pb_, cb_) ((cb_) < kEarlyX ? xr[pb_][(cb_) < kEarlyX ? (cb_) : 0] : xl[pb_][(cb_) >= kEarlyX ? (cb_) - kEarlyX : 0])
+    // masked: rows beyond M are not stored -- each pixel block's stores then sit behind a branch, and hipcc, which cannot
+    // know whether the other block's stores were issued, waits for all but 11 vector-memory operations before each of the second
+    // block's (a window of 11 stores in flight).  PERS tiles that lie inside M (all but possibly the last) take the unmasked form.
+    auto epilogue = [&](auto masked) __attribute__((always_inline)) {
+    constexpr bool kMasked = decltype(masked)::value;
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
     if constexpr (LNOUT) {
@@ -469,7 +549,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         float sum = 0.f;
 #pragma unroll
         for (int cb = 0; cb < C / 16; ++cb) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * cb + 4 * g4);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2s + 16 * cb + 4 * g4);
             const f32x4 v = ACX_XR(pb, cb);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[cb][pb][e] = v[e] + fmaf(acc[cb][pb][e], sinv2, bb[e]);
@@ -497,13 +577,13 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
                 acx_split_pair((acc[cb][pb][2 * e] - mean) * sc, (acc[cb][pb][2 * e + 1] - mean) * sc, uhi[e], ulo[e]);
                 acx_pair_swap16(uhi[e], ulo[e]);
             }
-            if (valid[pb]) *reinterpret_cast<uint4*>(op + cb * 64) = uint4{uhi[0], uhi[1], ulo[0], ulo[1]};
+            if (!kMasked || valid[pb]) *reinterpret_cast<uint4*>(op + cb * 64) = uint4{uhi[0], uhi[1], ulo[0], ulo[1]};
         }
-    } else if (valid[pb]) {
+    } else if (!kMasked || valid[pb]) {
         float* xp = x + mrow[pb] * C + 4 * g4;
 #pragma unroll
         for (int cb = 0; cb < C / 16; ++cb) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * cb + 4 * g4);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2s + 16 * cb + 4 * g4);
             f32x4 v = ACX_XR(pb, cb);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += fmaf(acc[cb][pb][e], sinv2, bb[e]);
@@ -511,20 +591,34 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
         }
     }
     }
+    };
+    if (PERS && (tile + 1) * kPixT <= M) epilogue(std::false_type{});
+    else epilogue(std::true_type{});
 #undef ACX_XR
     ACX_WSTAMP(4)
+    if (!has_next) break;
+    // (the stores above stay in flight: the wait at the end of the next tile's segment 0 allows for them)
+    tile += gridDim.x;
+    ACX_TILE_ROWS(tile)
+    first = false;
+    }
+#undef ACX_WDMA
+#undef ACX_Y_LOAD
+#undef ACX_BIAS_STAGE
+#undef ACX_TILE_ROWS
     ACX_WSTAMP_FLUSH
 }
 
-template <int C, int PT, bool LNOUT, int NPB>
-static int launch_wide_cfg(const BlockW& w, const float* y, float* x, long long M, void* ln_out, hipStream_t s) {
+template <int C, int PT, bool LNOUT, int NPB, bool PERS = false>
+static int launch_wide_cfg(const BlockW& w, const float* y, float* x, long long M, void* ln_out, hipStream_t s, int max_wgs = 0) {
     using Cfg = WideCfg<C, PT>;
     static_assert(Cfg::kLdsBytes <= kCuLdsBytes, "weight ring does not fit the LDS");
     static DeviceOnce once;
-    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_kernel<C, PT, LNOUT, NPB>, kCuLdsBytes));
+    ACX_TRY(set_max_dynamic_lds(once, &mlp_fused_wide_kernel<C, PT, LNOUT, NPB, PERS>, kCuLdsBytes));
     constexpr int kPixT = Cfg::kWaves * 16 * NPB;
-    const long long blocks = (M + kPixT - 1) / kPixT;
-    launch_kernel(&mlp_fused_wide_kernel<C, PT, LNOUT, NPB>, dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s,
+    long long blocks = (M + kPixT - 1) / kPixT;
+    if (PERS && blocks > max_wgs) blocks = max_wgs;      // one workgroup per CU this launch may count on; each walks its tiles
+    launch_kernel(&mlp_fused_wide_kernel<C, PT, LNOUT, NPB, PERS>, dim3((unsigned)blocks), dim3(Cfg::kThreads), kCuLdsBytes /* CU-exclusive */, s,
         y, x, reinterpret_cast<const char*>(w.wstream_s), w.b1, w.b2, M, 1.0f / (kSplitLnScale * w.w1s_scale),
         1.0f / (w.hid_scale * w.w2s_scale), w.hid_scale, reinterpret_cast<char*>(ln_out));
     ACX_HIP(hipGetLastError());
@@ -547,7 +641,15 @@ int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, fl
     if (const int f = tuning().wide_npb.load(std::memory_order_relaxed)) half = f == 1;
 #define ACX_GO(C_, LN_) (half ? launch_wide_cfg<C_, 1, LN_, 1>(w, y, x, M, LN_ ? ln_out : nullptr, s) : launch_wide_cfg<C_, 1, LN_, 2>(w, y, x, M, LN_ ? ln_out : nullptr, s))
     if (C == 384) return ln_out ? ACX_GO(384, true) : ACX_GO(384, false);
-    if (C == 192) return ln_out ? ACX_GO(192, true) : ACX_GO(192, false);
+    if (C == 192) {
+        // the persistent form once every CU of this launch's share has more than one tile to walk (ACX_WIDE_PERSIST = 0 | 1 forces)
+        const int share = cus / ways > 0 ? cus / ways : 1;
+        bool pers = !half && (M + 127) / 128 > share;
+        if (const int f = tuning().wide_pers.load(std::memory_order_relaxed)) pers = f == 1 && !half;
+        if (pers) return ln_out ? launch_wide_cfg<192, 1, true, 2, true>(w, y, x, M, ln_out, s, share)
+                                : launch_wide_cfg<192, 1, false, 2, true>(w, y, x, M, nullptr, s, share);
+        return ln_out ? ACX_GO(192, true) : ACX_GO(192, false);
+    }
 #undef ACX_GO
     ACX_FAIL(ACX_ERR_SHAPE, "wide fused MLP: unsupported channel count %d", C);
 }

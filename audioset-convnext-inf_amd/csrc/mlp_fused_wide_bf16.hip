@@ -35,7 +35,7 @@ struct WideBfCfg {
     static constexpr int kUnits = 2 * kSteps;               // fragment reads of a segment: (k-step, X tile) or (out tile, k-step): 4 kTiles = 2 kSteps
     static constexpr int kMfmas = kUnits * PT;              // MFMAs per segment
     static constexpr int kHalf = 64 * PT;                   // GELU micro-steps a segment carries
-    static constexpr size_t kLdsBytes = 3 * (size_t)kSegBytes + 4 * C * 4;
+    static constexpr size_t kLdsBytes = 3 * (size_t)kSegBytes + 4 * C * 4 + C * 4;      // ring, b1, b2
     static_assert(C % 32 == 0 && kUnits % kPieces == 0, "unit / piece bookkeeping");
     // W1 rows are 2 C bytes = C/8 chunks of 16 B: the XOR that spreads 16 consecutive rows over the LDS banks
     static constexpr int kSwzBits = (C % 128 == 0) ? 4 : ((C % 64 == 0) ? 3 : 2);
@@ -85,6 +85,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     using Cfg = WideBfCfg<C, PT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* b1s = reinterpret_cast<float*>(smem + 3 * Cfg::kSegBytes);   // [4C]
+    float* b2s = b1s + 4 * C;     // [C]: read by the epilogue (round 4: as loads from b2 inside its store loop they were one L2
+    // round trip per store -- hipcc waits for every outstanding vector-memory operation there, the previous store included)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -111,12 +113,17 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(0, p, 0)
 #pragma unroll
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(1, p, 1)
-    // 16 bytes per lane, every load of the staging issued before the first wait (a rolled scalar loop was 4C / 256 dependent round trips)
+    // bias staging: 16 bytes per lane, requested here (ahead of the tile's rows: vmcnt completes in order) and written to the LDS
+    // behind the LayerNorm, so that it has no wait of its own
+    constexpr int kB1Iters = (C + Cfg::kThreads - 1) / Cfg::kThreads;
+    float4 b1v[kB1Iters];
 #pragma unroll
-    for (int i0 = 0; i0 < C; i0 += Cfg::kThreads) {
-        const int i = i0 + tid;
-        if (i < C) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(b1)[i];
+    for (int q = 0; q < kB1Iters; ++q) {
+        const int i = q * Cfg::kThreads + tid;
+        b1v[q] = reinterpret_cast<const float4*>(b1)[i < C ? i : 0];
     }
+    static_assert(C / 4 <= Cfg::kThreads, "one float4 of b2 per thread");
+    const float4 b2v = reinterpret_cast<const float4*>(b2)[tid < C / 4 ? tid : 0];
 
     // ---- this wave's activations: lane (px = l31, half hh) holds channels 16s + 8hh .. +7 as 8 bf16, s = 0..C/16-1 ----
     f32x4 act[PT][Cfg::kSteps];
@@ -143,6 +150,13 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
             act[pt][s] = __builtin_bit_cast(f32x4, uint4{u4[0], u4[1], u4[2], u4[3]});
         }
     }
+
+#pragma unroll
+    for (int q = 0; q < kB1Iters; ++q) {
+        const int i = q * Cfg::kThreads + tid;
+        if (i < C) reinterpret_cast<float4*>(b1s)[i] = b1v[q];
+    }
+    if (tid < C / 4) reinterpret_cast<float4*>(b2s)[tid] = b2v;
 
     f32x16 acc[PT][Cfg::kTiles];
 #pragma unroll
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
             for (int t = 0; t < Cfg::kTiles; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 bb = *reinterpret_cast<const float4*>(b2 + 32 * t + 8 * q + 4 * hh);
+                    const float4 bb = *reinterpret_cast<const float4*>(b2s + 32 * t + 8 * q + 4 * hh);
                     float4 v;
                     if constexpr (kPrefetchX) v = xr[pt][4 * t + q];
                     else v = acx_ld4<ABF>(x, mrow[pt] * C + 4 * hh + 32 * t + 8 * q);
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int q = 2 * j + i;
-                        const float4 bb = *reinterpret_cast<const float4*>(b2 + 32 * t + 8 * q + 4 * hh);
+                        const float4 bb = *reinterpret_cast<const float4*>(b2s + 32 * t + 8 * q + 4 * hh);
                         v[i] = xr[pt][4 * t + q];
                         v[i].x += acc[pt][t][4 * q + 0] + bb.x;
                         v[i].y += acc[pt][t][4 * q + 1] + bb.y;

@@ -2,8 +2,8 @@
 # On the GPU box (via gpurun): the GPU suite, then the bench summary (twice), optionally the A/B of an environment switch.
 #   bash tools/quick_gpu.sh [tag] [pytest -k expression | "all" | "none"] [ENV=VALUE for an extra A/B bench]
 TAG=${1:-q}; SEL=${2:-all}; AB=$3
-if [ "$SEL" = all ]; then python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-elif [ "$SEL" != none ]; then python -m pytest tests -m gpu -x -q -k "$SEL" 2>&1 | tail -3; fi
+if [ "$SEL" = all ]; then python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3
+elif [ "$SEL" != none ]; then python -m pytest tests -m gpu -x -q -k "$SEL" 2>&1 | grep -E "passed|failed|error" | tail -3; fi
 summ() { python - "$1" <<'EOF2'
 import json, sys
 d = json.load(open(sys.argv[1]))

@@ -14,7 +14,12 @@ ProfScope::ProfScope(acx_ctx*, int, hipStream_t) : ctx(nullptr) {}
 ProfScope::~ProfScope() {}
 void prof_next_events(hipEvent_t* a, hipEvent_t* b) { *a = nullptr; *b = nullptr; }
 thread_local int tls_inflight_ways = 1;
-Tuning& tuning() { static Tuning t; return t; }
+Tuning& tuning() {     // the library's switches that matter here, straight from the environment
+    static Tuning t;
+    static bool init = false;
+    if (!init) { init = true; if (const char* e = getenv("ACX_WIDE_PERSIST")) t.wide_pers.store(e[0] == '1' ? 1 : 2); }
+    return t;
+}
 }
 
 int main(int argc, char** argv) {
@@ -75,14 +80,16 @@ int main(int argc, char** argv) {
         static unsigned long long st[2048 * 4 * 8];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(acx::acx_fw_stamps), sizeof(st));
         const char* names[8] = {"prologue", "phase-1 segments", "phase-2 segments", "segment-end wait+barrier", "epilogue", "-", "-", "-"};
-        const long long wgs = (M + 127) / 128 < 2048 ? (M + 127) / 128 : 2048;
+        long long wgs = (M + 127) / 128 < 2048 ? (M + 127) / 128 : 2048;
+        double per_tile = 1.0;      // persistent form: a workgroup's sums cover all its tiles
+        { const char* e = getenv("ACX_WIDE_PERSIST"); int cus = 256; if (C == 192 && !(e && e[0] == '0') && (M + 127) / 128 > cus) { per_tile = (double)((M + 127) / 128) / cus; wgs = cus; } }
         for (int w : {0, 3}) {
             double sum[8] = {0};
             for (int b = 0; b < wgs; ++b) for (int k = 0; k < 8; ++k) sum[k] += (double)st[(b * 4 + w) * 8 + k];
             double tot = 0; for (int k = 0; k < 5; ++k) tot += sum[k];
             printf("   wave %d: ticks per tile:", w);
-            for (int k = 0; k < 5; ++k) printf(" %s %.0f |", names[k], sum[k] / wgs);
-            printf(" total %.0f\n", tot / wgs);
+            for (int k = 0; k < 5; ++k) printf(" %s %.0f |", names[k], sum[k] / wgs / per_tile);
+            printf(" total %.0f\n", tot / wgs / per_tile);
         }
     }
 #endif
