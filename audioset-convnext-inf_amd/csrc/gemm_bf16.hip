@@ -138,6 +138,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af_[i]),    \
                                                                 __builtin_bit_cast(bf16x8, bf_[j]), acc[i][j], 0, 0, 0); \
     }
+    // The LDS-DMA pieces of the NEXT k-tile are threaded one by one through the MFMAs of this tile's first two groups (A pieces in
+    // the first, B pieces in the second), as in gemm.hip: issued as a burst of 7 at the top of the tile they stall the wave for
+    // ~700 cycles while its SIMD partner, in lockstep, stalls on its own burst (round 4; the burst form ran 0.29-0.33 of 2.5 PF).
+#define ACX_MFMA_GROUP_DMA(af_, bf_, src_, n_, koff_, dst_)                                            \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                               \
+            if (i * TN + j < (n_)) {                                                                   \
+                lds_dma16_b(src_[i * TN + j] + (koff_), (dst_) + (i * TN + j) * 8 * kBfRowBytes);      \
+                __builtin_amdgcn_sched_barrier(0);                                                     \
+            }                                                                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af_[i]),    \
+                                                                __builtin_bit_cast(bf16x8, bf_[j]), acc[i][j], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+        }                                                                                              \
+    }
+    static_assert(A_DMA <= TM * TN && B_DMA <= TM * TN, "one piece per MFMA of a group at most");
 #define ACX_TOUCH(af_, bf_)   /* see gemm.hip: hipcc only emits lgkmcnt(0) next to an LDS-DMA */      \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af_[i]));                \
@@ -159,14 +176,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
         const char* bb = Bs + (kt & 1) * B_TILE + b_frag_off;
         const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
         const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
-        ACX_DMA_TILE((kt + 1) * kBfBK, (kt + 1) & 1);
+        const int k1 = (kt + 1) * kBfBK;
+        long long koff1 = k1;
+        if (GATHER) {
+            const int qd = k1 / p.Cp;
+            koff1 = (long long)((qd >> 1) * p.W + (qd & 1)) * p.Cp + (k1 - qd * p.Cp);
+        }
+        char* adn = a_dst + ((kt + 1) & 1) * A_TILE;
+        char* bdn = b_dst + ((kt + 1) & 1) * B_TILE;
         __builtin_amdgcn_sched_barrier(0);
-        ACX_MFMA_GROUP(af0, bf0)
+        ACX_MFMA_GROUP_DMA(af0, bf0, a_src, A_DMA, koff1, adn)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af1, bf1)
         ACX_READ_FRAGS(af0, bf0, ab, bb, 2)
         __builtin_amdgcn_sched_barrier(0);
-        ACX_MFMA_GROUP(af1, bf1)
+        ACX_MFMA_GROUP_DMA(af1, bf1, b_src, B_DMA, (long long)k1, bdn)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af0, bf0)
         ACX_READ_FRAGS(af1, bf1, ab, bb, 3)
@@ -199,6 +223,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
 #undef ACX_DMA_TILE
 #undef ACX_READ_FRAGS
 #undef ACX_MFMA_GROUP
+#undef ACX_MFMA_GROUP_DMA
 #undef ACX_TOUCH
 
     // ---- epilogue: D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ---------------------
