@@ -586,6 +586,10 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
             }
         }
 
+        // (a tile whose 32 rows all lie inside M stores without a mask: behind `if (valid)` every store is a basic block of its
+        // own and hipcc's waits for the residual values then also wait for the stores before them)
+        auto epilogue = [&](auto masked) __attribute__((always_inline)) {
+        constexpr bool kMasked = decltype(masked)::value;
         // ---- epilogue: lane (px, hh), tile t, q: channels 32 t + 8 q + 4 hh .. + 3  ->  x = x + out + b2 ----
         if constexpr (LNOUT) {
             float sum = 0.f;
@@ -622,9 +626,9 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
                             o[w] = pack_bf16((acc[t][8 * j + 4 + 2 * w] - mean) * rstd, (acc[t][8 * j + 4 + 2 * w + 1] - mean) * rstd);
                             acx_pair_swap(e[w], o[w]);
                         }
-                        if (valid) *reinterpret_cast<uint4*>(op + 32 * t + 16 * j) = uint4{e[0], e[1], o[0], o[1]};
+                        if (!kMasked || valid) *reinterpret_cast<uint4*>(op + 32 * t + 16 * j) = uint4{e[0], e[1], o[0], o[1]};
                     }
-                if (valid)
+                if (!kMasked || valid)
                     for (int c = C + 8 * hh; c < ld_out; c += 16)      // zero the K padding of the downsample GEMM's operand rows
                         *reinterpret_cast<uint4*>(ln_out + mrow * (long long)ld_out + c) = uint4{0u, 0u, 0u, 0u};
             }
@@ -649,14 +653,17 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
                         unsigned o[2] = {acx_pack_bf16x2(v[1].x, v[1].y), acx_pack_bf16x2(v[1].z, v[1].w)};
                         acx_pair_swap(e[0], o[0]);
                         acx_pair_swap(e[1], o[1]);
-                        if (valid)
+                        if (!kMasked || valid)
                             *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(x) + mrow * C + 8 * hh + 32 * t + 16 * j) = uint4{e[0], e[1], o[0], o[1]};
-                    } else if (valid) {
+                    } else if (!kMasked || valid) {
                         acx_st4<false>(x, mrow * C + 4 * hh + 32 * t + 16 * j, v[0]);
                         acx_st4<false>(x, mrow * C + 4 * hh + 32 * t + 16 * j + 8, v[1]);
                     }
                 }
         }
+        };
+        if ((tile + 1) * 32 <= M) epilogue(std::false_type{});
+        else epilogue(std::true_type{});
     }
 #undef ACX_B8
 #undef ACX_W1_RD

@@ -8,8 +8,8 @@ for pair in fp32_split:split bf16a:bf16a bf16:bf16 fp32:fp32; do
   P=${pair%%:*}; N=${pair##*:}; O=gpurun_out/final_$P
   [ -f $O/bench.json ] && [ -d $O/stats_onestream ] || continue
   cp $O/bench.json profiles/${TAG}_${N}_bench.json
-  cp $(find $O/stats -name '*kernel_stats.csv' | head -1) profiles/${TAG}_${N}_kernel_stats.csv
-  cp $(find $O/stats_onestream -name '*kernel_stats.csv' | head -1) profiles/${TAG}_${N}_onestream_kernel_stats.csv
+  cp $(ls -t $(find $O/stats -name "*kernel_stats.csv") | head -1) profiles/${TAG}_${N}_kernel_stats.csv
+  cp $(ls -t $(find $O/stats_onestream -name "*kernel_stats.csv") | head -1) profiles/${TAG}_${N}_onestream_kernel_stats.csv
   cp $O/pmc_per_kernel.csv profiles/${TAG}_${N}_pmc_per_kernel.csv
   cp $O/traffic.json profiles/${TAG}_${N}_traffic.json
   echo "stashed $P -> profiles/${TAG}_${N}_*"
