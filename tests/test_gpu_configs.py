@@ -313,3 +313,45 @@ def test_small_launch_tile_shapes_are_invisible(synth_sd, B, L, precision, monke
         for var in ("ACX_WIDE_NPB", "ACX_GEMM_MI", "ACX_DW_STREAM"):
             monkeypatch.delenv(var, raising=False)
         refresh()
+
+
+@pytest.mark.parametrize("B,L", [(24, 160000), (3, 96123)])
+def test_persistent_fused_mlp_is_invisible(synth_sd, B, L, monkeypatch):
+    """Stage 1's fused MLP (C = 192, fp32_split) runs as a persistent kernel once a CU has more than one tile to walk
+    (mlp_fused_wide.hip, PERS): the next tile's rows are requested two segments ahead, the weight ring runs on across tiles and a
+    tile's stores stay in flight under the next one -- all of it resting on hand-counted s_waitcnt vmcnt(N).  24 clips of 5 s give
+    every workgroup several tiles and a last tile that is only partly inside M; 3 clips of 3 s force the form onto a launch whose
+    workgroups have one tile each.  ACX_WIDE_PERSIST = 0 | 1 selects the form (ACX_WIDE_NPB = 2 keeps the 128-pixel tile that the
+    persistent form is written for): same arithmetic, same bits, also on a second stream and under two sub-batches."""
+    wav = synth.synth_waveforms(B, L, seed=1200 + B).cuda()
+
+    def run(m):
+        out = (m(wav)["clipwise_logits"].clone(), m.forward_frame_embeddings(wav).clone())
+        torch.cuda.synchronize()
+        return out
+
+    from audioset_convnext_inf_amd import _ffi
+    refresh = _ffi.lib().acx_tuning_refresh
+    names = ("ACX_WIDE_NPB", "ACX_WIDE_PERSIST", "ACX_SPLIT_WAYS")
+    for var in names:
+        monkeypatch.delenv(var, raising=False)
+    try:
+        monkeypatch.setenv("ACX_WIDE_NPB", "2")
+        monkeypatch.setenv("ACX_WIDE_PERSIST", "0")
+        refresh()
+        ref = run(make_model(synth_sd, "fp32_split"))
+        monkeypatch.setenv("ACX_WIDE_PERSIST", "1")
+        refresh()
+        for ways in (None, "1", "3"):        # (read when the context is created)
+            if ways is None:
+                monkeypatch.delenv("ACX_SPLIT_WAYS", raising=False)
+            else:
+                monkeypatch.setenv("ACX_SPLIT_WAYS", ways)
+            m = make_model(synth_sd, "fp32_split")
+            for rep in range(3):
+                got = run(m)
+                assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (ways, rep)
+    finally:
+        for var in names:
+            monkeypatch.delenv(var, raising=False)
+        refresh()
