@@ -195,7 +195,7 @@ ACX_API int acx_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, in
  * dense matrix, which is applied as it is).  Any pointer may be NULL. */
 ACX_API int acx_frontend_info(const acx_ctx* ctx, int* dense_dft, float* stft_deviation, int* mel_taps);
 
-/* Diagnostics.  The tile-shape A/B switches ACX_GEMM_MI, ACX_WIDE_NPB, ACX_GEMM_32X32 and ACX_DW_STREAM are read from the
+/* Diagnostics.  The tile-shape A/B switches ACX_GEMM_MI, ACX_WIDE_NPB, ACX_WIDE_PERSIST, ACX_GEMM_32X32 and ACX_DW_STREAM are read from the
  * environment once, at the first acx_create; this re-reads them (tests force every tile shape through it and require
  * bit-identical results).  Launches never touch the environment.  No reference counterpart. */
 ACX_API int acx_tuning_refresh(void);
