@@ -15,7 +15,17 @@ namespace acx {
 constexpr int kFrontWaves = 4;
 
 
-constexpr int kMelLds = 1024;        // banded mel weights kept in LDS when they fit (librosa's 224-bin bank: 884)
+// Mel weights in the LDS.  Fast form (round 4): bin m = lane + 64 i of group i has at most kMelTaps[i] taps -- true of librosa's
+// 224-bin bank at 32 kHz (1 / 3 / 8 / 14) -- and its weights sit zero-padded at [group base + 64 q + lane]: four unrolled loops
+// of fixed length whose 52 LDS reads are all in flight together, instead of four run-time loops of 26 iterations in all, each a
+// dependent LDS round trip (a fifth of a frame's time at two waves per SIMD).  A padded tap multiplies a finite spectrum value
+// (or, past bin 512, finite second-pass data of the same frame) by zero: same sums, same bits.  Any other bank takes the general
+// loops over the banded table (kept in the LDS when it fits).
+constexpr int kMelTaps[4] = {1, 3, 8, 14};
+constexpr int kMelBase[5] = {0, 64, 256, 768, 1664};
+constexpr int kMelLds = 1664;
+
+struct __attribute__((packed, aligned(4))) FrontF2 { float a, b; };
 
 struct FrontLds {
     float melw[kMelLds];
@@ -38,8 +48,6 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
     const int wave = tid >> 6;
     for (int i = tid; i < 1024; i += 256) lds.tw[i] = cf_make(twiddle[2 * i], twiddle[2 * i + 1]);
     const bool mel_in_lds = mel_w_len <= kMelLds;      // else the filter loop reads the weights from global memory
-    if (mel_in_lds)
-        for (int i = tid; i < mel_w_len; i += 256) lds.melw[i] = mel_w[i];
 
     // this lane's mel bins (224 = 3.5 x 64) and their band descriptors
     int mstart[4], mlen[4], moff[4];
@@ -53,6 +61,19 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         moff[i] = ok ? mel_off[m] : 0;
         msc[i] = ok ? bn_scale[m] : 0.f;
         msh[i] = ok ? bn_shift[m] : 0.f;
+    }
+    // every wave holds all 224 bins (lane + 64 i): the choice of the filter loop is the same in every wave
+    const bool mel_fast = __all(mlen[0] <= kMelTaps[0] && mlen[1] <= kMelTaps[1] && mlen[2] <= kMelTaps[2] && mlen[3] <= kMelTaps[3]);
+    if (mel_fast) {
+        for (int e = tid; e < kMelLds; e += 256) {
+            const int i = e < kMelBase[1] ? 0 : (e < kMelBase[2] ? 1 : (e < kMelBase[3] ? 2 : 3));
+            const int rel = e - kMelBase[i], q = rel >> 6, m = (rel & 63) + 64 * i;
+            float wv = 0.f;
+            if (m < kMels && q < mel_len[m]) wv = mel_w[mel_off[m] + q];
+            lds.melw[e] = wv;
+        }
+    } else if (mel_in_lds) {
+        for (int i = tid; i < mel_w_len; i += 256) lds.melw[i] = mel_w[i];
     }
     float2 hw[8];   // hann for this lane's 16 samples (same for every frame)
 #pragma unroll
@@ -91,7 +112,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 int n = 2 * (lane + 64 * r);
-                v[r] = cf_make(xs[n] * hw[r].x, xs[n + 1] * hw[r].y);
+                const FrontF2 xv = *reinterpret_cast<const FrontF2*>(xs + n);     // one 8-byte load (4-byte aligned: clips of odd length)
+                v[r] = cf_make(xv.a * hw[r].x, xv.b * hw[r].y);
             }
         } else {
 #pragma unroll
@@ -141,7 +163,11 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         for (int i = 0; i < 4; ++i) {
             float acc = 0.f;
             const float* p = P + mstart[i];
-            if (mel_in_lds) {
+            if (mel_fast) {
+                const float* w = lds.melw + kMelBase[i] + lane;
+#pragma unroll
+                for (int q = 0; q < kMelTaps[i]; ++q) acc = fmaf(p[q], w[64 * q], acc);
+            } else if (mel_in_lds) {
                 const float* w = lds.melw + moff[i];
                 for (int q = 0; q < mlen[i]; ++q) acc = fmaf(p[q], w[q], acc);
             } else {
