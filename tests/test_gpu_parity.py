@@ -115,6 +115,30 @@ def test_stem_kernel(ctx, taps):
     assert maxdiff(nchw(out), ref) < LAYER_TOL
 
 
+@pytest.mark.parametrize("B,T", [(1, 101), (3, 23), (1, 5), (5, 1001), (64, 311)])
+def test_stem_kernel_shapes(ctx, synth_sd, B, T):
+    """The stem walks output rows in PAIRS (two rows per workgroup step, two pixels per 32-lane group: stem.hip): odd row counts
+    (1 x 27, 3 x 7 rows), a single pair, pairs that straddle two clips, time rows in the zero padding at both ends, and launches
+    whose workgroups walk several pairs -- against Conv2d(1, 96, 4x4, stride 4, padding (4, 0)) + channels-first LayerNorm in
+    float64 (convnext.py:688-691, :536-541)."""
+    g = torch.Generator().manual_seed(100 * B + T)
+    x = (torch.randn(B, T, 224, generator=g) * 3.0).cuda()
+    H0 = (T + 8 - 4) // 4 + 1
+    out = torch.full((B, H0, 56, 96), float("nan"), device="cuda")
+    _ffi.check(_ffi.lib().acx_stem_ln(ctx.handle, _ffi.ptr(x), B, T, _ffi.ptr(out), sp()))
+    w = synth_sd["downsample_layers.0.0.weight"].double()
+    b = synth_sd["downsample_layers.0.0.bias"].double()
+    lw = synth_sd["downsample_layers.0.1.weight"].double()
+    lb = synth_sd["downsample_layers.0.1.bias"].double()
+    y = torch.nn.functional.conv2d(x.cpu().double()[:, None], w, b, stride=4, padding=(4, 0))      # (B, 96, H0, 56)
+    u = y.mean(1, keepdim=True)
+    v = (y - u).pow(2).mean(1, keepdim=True)
+    ref = (y - u) / torch.sqrt(v + 1e-6) * lw[None, :, None, None] + lb[None, :, None, None]
+    assert ref.shape[2] == H0
+    assert torch.isfinite(out).all()
+    assert float((out.cpu().double().permute(0, 3, 1, 2) - ref).abs().max()) < LAYER_TOL
+
+
 @pytest.mark.parametrize("s", [0, 1, 2, 3])
 def test_dwconv_and_ln_stats(ctx, taps, synth_sd, s):
     x = nhwc(taps["ds%d" % s])
