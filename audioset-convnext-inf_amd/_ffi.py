@@ -46,8 +46,10 @@ SIGNATURES = {
     "acx_comm_init": (_c_int, [_vp, _c_int, _c_int, _vp]),
     "acx_allgather": (_c_int, [_vp, _vp, _vp, _c_sz, _vp]),
     "acx_comm_info": (_c_int, [_vp, _pint, _pint]),
+    "acx_pcm16_to_f32": (_c_int, [_vp, _vp, _c_i64, _vp]),
     "acx_frontend_info": (_c_int, [_vp, _pint, ctypes.POINTER(ctypes.c_float), _pint]),
     "acx_tuning_refresh": (_c_int, []),
+    "acx_test_fail_sub": (_c_int, [_c_int]),
     "acx_profile_enable": (_c_int, [_vp, _c_int]),
     "acx_profile_read": (_c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64)]),
 }

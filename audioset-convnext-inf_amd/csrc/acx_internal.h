@@ -169,9 +169,6 @@ struct acx_ctx {
     float stft_deviation = 0.f;   // max |stored - hann x DFT| found at acx_finalize
     float* d_stft_w = nullptr;    // [kDenseN][1024]: rows 0..512 conv_real, 513..1025 conv_imag, the rest zero
     float* d_stft_zero = nullptr; // [kDenseN] zero bias
-    void* fe_scratch = nullptr;   // acx_logmel_bn0 only (the forward uses the caller's workspace): frames + spectrum, grown on demand
-    size_t fe_scratch_bytes = 0;
-    std::mutex fe_mutex;
     // stem
     float* d_stem_w = nullptr;    // [96][16]
     float* d_stem_b = nullptr;    // [96]
@@ -199,6 +196,7 @@ struct acx_ctx {
     struct AuxEntry { Aux a; unsigned long long stamp = 0; int users = 0; };
     std::map<hipStream_t, AuxEntry> aux;
     unsigned long long aux_clock = 0;
+    std::vector<Aux> aux_retired;   // evicted fork / join sets, released by acx_destroy
     std::mutex aux_mutex;
     // identity affine for acx_logmel_bn0(apply_bn0 = 0) (tests): per context, i.e. per device
     float* d_bn_one = nullptr;
@@ -226,7 +224,7 @@ struct Tuning {
     std::atomic<int> gemm_mi{0};       // ACX_GEMM_MI = 1 | 2 | 4: row blocks per wave of the split / bf16 GEMM tiles (0: by launch size)
     std::atomic<int> wide_npb{0};      // ACX_WIDE_NPB = 1 | 2: pixel blocks per wave of the wide fused MLP (0: by launch size)
     std::atomic<int> gemm_32x32{0};    // ACX_GEMM_32X32 = 1: the 32x32x16 form of the split GEMM
-    std::atomic<int> fail_sub{-1};     // ACX_TEST_FAIL_SUB = i: acx_forward reports a failure after queueing sub-batch i (error-path tests)
+    std::atomic<int> fail_sub{-1};     // acx_test_fail_sub(i): acx_forward reports a failure after queueing sub-batch i (error-path tests; never read from the environment)
     std::atomic<int> wide_pers{0};     // ACX_WIDE_PERSIST: 1 = persistent wide fused MLP wherever it exists, 2 = never; 0 = by launch size
     std::atomic<int> dw_stream{-1};    // ACX_DW_STREAM = 0 | 1: forces the tile / column-streaming depthwise kernels (-1: by launch size)
 };
@@ -336,6 +334,7 @@ int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const void* y
 int launch_pool_head(acx_ctx* c, const float* x, int B, int H3, float* scene, float* logits, float* probs,
                      hipStream_t s);
 int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, int W, int C, hipStream_t s);
+int launch_pcm16_to_f32(const short* in, float* out, long long n, hipStream_t s);
 
 // number of CUs of the current device (one persistent workgroup each), cached per device
 inline int cu_count_of_current_device(int* out) {

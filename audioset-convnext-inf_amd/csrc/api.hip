@@ -28,7 +28,6 @@ void tuning_reload() {
     t.wide_pers.store(digit("ACX_WIDE_PERSIST", "01", -1) < 0 ? 0 : (digit("ACX_WIDE_PERSIST", "01", 0) == 1 ? 1 : 2), std::memory_order_relaxed);
     t.gemm_32x32.store(digit("ACX_GEMM_32X32", "1", 0), std::memory_order_relaxed);
     t.dw_stream.store(digit("ACX_DW_STREAM", "01", -1), std::memory_order_relaxed);
-    t.fail_sub.store(digit("ACX_TEST_FAIL_SUB", "0123", -1), std::memory_order_relaxed);
 }
 
 void set_error(const char* fmt, ...) {
@@ -715,8 +714,8 @@ void acx_destroy(acx_ctx* c) {
     for (auto& r : c->prof.recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
     for (auto& kv : c->aux) destroy_aux(kv.second.a);
+    for (auto& a : c->aux_retired) destroy_aux(a);
     comm_release(c);
-    if (c->fe_scratch) (void)hipFree(c->fe_scratch);
     delete c;
 }
 
@@ -830,8 +829,10 @@ static int get_aux(acx_ctx* c, hipStream_t st, acx_ctx::Aux* out, bool* found) {
                 if (d->first != nullptr && d->second.users == 0 && (victim == c->aux.end() || d->second.stamp < victim->second.stamp))
                     victim = d;
             if (victim != c->aux.end()) {
-                for (auto sd : victim->second.a.streams) if (sd) (void)hipStreamSynchronize(sd);
-                destroy_aux(victim->second.a);
+                // retired, not destroyed: destroying a stream that still has work means synchronising it, which stalls every
+                // forward waiting for aux_mutex and is an illegal call while ANY stream of the process captures in global
+                // mode.  A set is two streams and three events; acx_destroy releases the retired ones.
+                c->aux_retired.push_back(victim->second.a);
                 c->aux.erase(victim);
             }
         }
@@ -932,7 +933,7 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
             ws_off += pi.total;
             b_off += Bi;
             if (rc == ACX_OK && tuning().fail_sub.load(std::memory_order_relaxed) == i) {
-                set_error("test hook ACX_TEST_FAIL_SUB: failure injected after sub-batch %d", i);
+                set_error("test hook acx_test_fail_sub: failure injected after sub-batch %d", i);
                 rc = ACX_ERR_STATE;
             }
         }
@@ -1021,6 +1022,12 @@ int acx_nhwc_to_nchw(const float* x, float* out, int B, int H, int Wd, int C, vo
     return launch_nhwc_to_nchw(nullptr, x, out, B, H, Wd, C, (hipStream_t)stream);
 }
 
+int acx_pcm16_to_f32(const int16_t* pcm, float* out, int64_t n, void* stream) {
+    if (!pcm || !out || n < 0) ACX_FAIL(ACX_ERR_ARG, "acx_pcm16_to_f32: bad argument");
+    if (n == 0) return ACX_OK;
+    return launch_pcm16_to_f32(pcm, out, n, (hipStream_t)stream);
+}
+
 int acx_frontend_info(const acx_ctx* c, int* dense_dft, float* stft_deviation, int* mel_taps) {
     ACX_TRY(need_ready(c));
     if (dense_dft) *dense_dft = c->dense_stft ? 1 : 0;
@@ -1031,6 +1038,12 @@ int acx_frontend_info(const acx_ctx* c, int* dense_dft, float* stft_deviation, i
 
 int acx_tuning_refresh(void) {
     tuning_reload();
+    return ACX_OK;
+}
+
+int acx_test_fail_sub(int sub) {
+    if (sub < -1 || sub >= acx_ctx::kMaxSplitWays) ACX_FAIL(ACX_ERR_ARG, "acx_test_fail_sub: sub-batch index %d", sub);
+    tuning().fail_sub.store(sub, std::memory_order_relaxed);
     return ACX_OK;
 }
 

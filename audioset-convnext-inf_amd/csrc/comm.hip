@@ -7,6 +7,8 @@
 // librccl.so is opened on first use (dlopen): libacx.so itself has no link-time dependency on it, a single-GPU process never
 // loads it.  No CUDA-compat layer: these are RCCL's own entry points (the nccl* names ARE RCCL's API).
 #include <dlfcn.h>
+#include <link.h>
+#include <cstdio>
 #include <cstring>
 
 #include "acx_internal.h"
@@ -29,10 +31,28 @@ int load_rccl(Rccl** out) {
     static std::once_flag once;
     static const char* err = nullptr;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // One RCCL per process: if a copy is already mapped (torch ships its own next to libtorch and torch.distributed has
+        // loaded it), bind to THAT one -- by soname first, then by walking the loaded objects -- and open a new one only when
+        // none is (a plain C caller: /opt/rocm/lib).  Two instances would each keep their own communicator tables and
+        // bootstrap state.
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            r.so = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
             if (r.so) break;
         }
+        if (!r.so) {
+            static char found[1024];
+            found[0] = 0;
+            dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void*) -> int {
+                if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl.so")) { std::snprintf(found, sizeof found, "%s", info->dlpi_name); return 1; }
+                return 0;
+            }, nullptr);
+            if (found[0]) r.so = dlopen(found, RTLD_NOW | RTLD_NOLOAD);
+        }
+        if (!r.so)
+            for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+                r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (r.so) break;
+            }
         if (!r.so) { err = "librccl.so not found (dlopen)"; return; }
         r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(r.so, "ncclGetUniqueId"));
         r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(r.so, "ncclCommInitRank"));

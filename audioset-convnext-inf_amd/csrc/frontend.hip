@@ -63,7 +63,12 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         msh[i] = ok ? bn_shift[m] : 0.f;
     }
     // every wave holds all 224 bins (lane + 64 i): the choice of the filter loop is the same in every wave
-    const bool mel_fast = __all(mlen[0] <= kMelTaps[0] && mlen[1] <= kMelTaps[1] && mlen[2] <= kMelTaps[2] && mlen[3] <= kMelTaps[3]);
+    // (the unrolled loops read kMelTaps[i] power values from mstart[i] on for EVERY bin and rely on zero weights for the padded
+    // taps: a padded tap past the 513 power bins the frame wrote would multiply uninitialised LDS -- NaN bits times 0 is NaN --
+    // so a bank with such a bin takes the general loops)
+    const bool mel_fast = __all(mlen[0] <= kMelTaps[0] && mlen[1] <= kMelTaps[1] && mlen[2] <= kMelTaps[2] && mlen[3] <= kMelTaps[3] &&
+                                mstart[0] + kMelTaps[0] <= kBins && mstart[1] + kMelTaps[1] <= kBins &&
+                                mstart[2] + kMelTaps[2] <= kBins && mstart[3] + kMelTaps[3] <= kBins);
     if (mel_fast) {
         for (int e = tid; e < kMelLds; e += 256) {
             const int i = e < kMelBase[1] ? 0 : (e < kMelBase[2] ? 1 : (e < kMelBase[3] ? 2 : 3));
@@ -235,20 +240,23 @@ __global__ __launch_bounds__(256) void spec_to_logmel_kernel(const float* __rest
 static int launch_logmel_dense(acx_ctx* c, const float* wav, int B, int64_t L, int T, float* out, bool bn, hipStream_t s,
                                float* frames, float* spec) {
     const long long nframes = (long long)B * T;
-    if (!frames || !spec) {          // per-kernel entry point: the context's own scratch, grown on demand
+    // per-kernel entry point (acx_logmel_bn0; the forward passes its own workspace): frames + spectrum of THIS call, allocated and
+    // released in stream order on `s` -- calls on different streams or threads never share scratch (one grown-on-demand
+    // buffer per context was shared by every call in flight)
+    void* call_scratch = nullptr;
+    if (!frames || !spec) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (s != nullptr && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
             ACX_FAIL(ACX_ERR_STATE, "acx_logmel_bn0 (dense-DFT frontend) cannot run inside a stream capture: use acx_forward");
-        std::lock_guard<std::mutex> lock(c->fe_mutex);
         const size_t need = (size_t)nframes * (kNFFT + kDenseN) * 4;
-        if (c->fe_scratch_bytes < need) {
-            if (c->fe_scratch) { ACX_HIP(hipDeviceSynchronize()); (void)hipFree(c->fe_scratch); c->fe_scratch = nullptr; c->fe_scratch_bytes = 0; }
-            ACX_HIP(hipMalloc(&c->fe_scratch, need));
-            c->fe_scratch_bytes = need;
-        }
-        frames = reinterpret_cast<float*>(c->fe_scratch);
+        ACX_HIP(hipMallocAsync(&call_scratch, need, s));
+        frames = reinterpret_cast<float*>(call_scratch);
         spec = frames + (size_t)nframes * kNFFT;
     }
+    struct ScratchFree {        // every exit below (error returns included) hands the bytes back behind the launches queued so far
+        void* p; hipStream_t s;
+        ~ScratchFree() { if (p) (void)hipFreeAsync(p, s); }
+    } scratch_free{call_scratch, s};
     ProfScope ps(c, ACX_K_FRONTEND, s);
     long long blocks = nframes < 4096 ? nframes : 4096;
     launch_kernel(&frames_kernel, dim3((unsigned)blocks), dim3(256), 0, s, wav, L, T, nframes, frames);

@@ -144,6 +144,39 @@ int launch_nhwc_to_nchw(acx_ctx* c, const float* x, float* out, int B, int H, in
     return ACX_OK;
 }
 
+// Stored clips -> model input: AudioSet shards hold int16 PCM and the reference scales by 1 / 32767 on the host
+// (utilities.py:226-227 `int16_to_float32`: (x / 32767.0).astype(np.float32), numpy promotes to float64).  Here the clips cross
+// PCIe as int16 and are widened on the GPU: float(double(x) / 32767.0) -- the same two roundings, so the same bits -- 8 samples
+// (16 bytes in, 32 out) per thread and step; the tail of an odd-length buffer sample by sample.
+__global__ __launch_bounds__(256) void pcm16_to_f32_kernel(const short* __restrict__ in, float* __restrict__ out, long long n) {
+    const long long n8 = n >> 3;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const uint4 u = reinterpret_cast<const uint4*>(in)[i];
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+        float r[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            r[2 * q] = (float)((double)(short)(w[q] & 0xffffu) / 32767.0);
+            r[2 * q + 1] = (float)((double)(short)(w[q] >> 16) / 32767.0);
+        }
+        reinterpret_cast<float4*>(out)[2 * i] = make_float4(r[0], r[1], r[2], r[3]);
+        reinterpret_cast<float4*>(out)[2 * i + 1] = make_float4(r[4], r[5], r[6], r[7]);
+    }
+    for (long long i = (n8 << 3) + blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (float)((double)in[i] / 32767.0);
+}
+
+int launch_pcm16_to_f32(const short* in, float* out, long long n, hipStream_t s) {
+    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        ACX_FAIL(ACX_ERR_ARG, "acx_pcm16_to_f32: buffers must be 16-byte aligned");
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;
+    launch_kernel(&pcm16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n);
+    ACX_HIP(hipGetLastError());
+    return ACX_OK;
+}
+
 // element-wise fp32 <-> bf16 (round to nearest even): the per-layer entry points of the C ABI keep fp32 tensors in every mode
 // and convert at their boundary when the activations live in HBM as bf16 (ACX_PREC_BF16_ACT)
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, long long n4) {

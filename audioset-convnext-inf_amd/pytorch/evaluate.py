@@ -25,30 +25,52 @@ def move_data_to_device(x, device):
 
 
 class _Stager(object):
-    """Waveform batches -> device through three pinned host buffers.  `to_pinned` runs in the reader thread (a chunked,
-    multi-threaded copy: numpy releases the GIL), `to_device` in the caller: an asynchronous copy on its own stream, beside
-    the model's work on the previous batch.  int16 batches (data_generator.evaluate_batches(device_cast=True)) cross PCIe as
-    they are and become float32 on the GPU by the arithmetic of utilities.int16_to_float32 (/32767 in double precision,
-    one rounding to float32); float32 batches are copied as they are.  A buffer comes up for rewriting three batches later;
-    `to_pinned` first waits for the event recorded behind the asynchronous copy that last READ it (with a warm
-    model and fast page-cache reads nothing else orders the reader thread behind that DMA)."""
-    kCopyThreads = 4
+    """Waveform batches -> device through a ring of pinned host buffers that lives as long as the process (one stager per
+    device: `stager_for`).  `to_pinned` runs in the reader thread, `to_device` in the caller: an asynchronous copy on its own
+    stream, beside the model's work on the previous batch.
+
+    How a batch reaches its pinned buffer: kReaders threads copy row blocks (numpy releases the GIL in
+    copyto) -- out of the page-cache mapping for a memory-mapped .npy shard, out of memory otherwise; a batch that already IS a
+    pinned torch tensor goes to the device as it is.  Measured (tools/feed_bench.py, profiles/r05_a_feed_bench.txt): the copy
+    out of the mapping moves 7.5 GB/s per process on first touch and 28 GB/s on mapped pages in the build container (8 cores),
+    MORE than `preadv` of the same bytes straight into the buffer (4.3 / 18 GB/s), so there is no read-into-pinned path; what
+    round 4's sweep lost was not this copy but three things around it: every forward() pinned a fresh set of buffers (3 x 164 MB
+    of page pinning inside a sweep of 8 batches), batches were staged one ahead only, and the int16 -> float32 widening ran as
+    three element-wise torch passes over 82 M samples (3 GB of HBM traffic per batch) on the compute stream.
+    int16 batches (data_generator.evaluate_batches(device_cast=True)) cross PCIe as they are and are widened on the GPU by
+    the library (acx_pcm16_to_f32: float(double(x) / 32767), the arithmetic of utilities.int16_to_float32, one kernel, 0.5 GB
+    of traffic per 256 clips instead of torch's three element-wise passes); float32 batches are copied as they are.  A buffer
+    comes up for rewriting kRing batches later; `to_pinned` first waits for the event recorded behind the asynchronous copy
+    that last READ it."""
+    kReaders = 8
+    kRing = 4           # two batches staged ahead + the one being staged + the one the copy engine reads
 
     def __init__(self, device):
         self.device = device
-        self.pinned = [None, None, None]
-        self.ready = [None, None, None]     # per buffer: event behind the H2D copy that read it last
+        self.pinned = [None] * self.kRing
+        self.ready = [None] * self.kRing    # per buffer: event behind the H2D copy that read it last
         self.turn = 0
         self.copy_stream = None
         self.pool = None
 
     def staged(self, x):
+        if self.device.type != "cuda":
+            return False
+        if isinstance(x, torch.Tensor):
+            return x.dtype in (torch.int16, torch.float32) and x.dim() == 2 and x.is_pinned()
         x = np.asarray(x)
-        return self.device.type == "cuda" and x.dtype in (np.int16, np.float32) and x.ndim == 2
+        return x.dtype in (np.int16, np.float32) and x.ndim == 2
+
+    def _pool(self):
+        if self.pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(self.kReaders)
+        return self.pool
 
     def to_pinned(self, x):
-        x = np.asarray(x)
-        n = x.size
+        if isinstance(x, torch.Tensor) and x.is_pinned():
+            return x, None
+        n = int(np.prod(x.shape))
         slot = self.turn
         buf = self.pinned[slot]
         ev = self.ready[slot]
@@ -57,17 +79,15 @@ class _Stager(object):
             self.ready[slot] = None
         want = torch.int16 if x.dtype == np.int16 else torch.float32
         if buf is None or buf.dtype != want or buf.numel() < n:
-            buf = torch.empty(n, dtype=want).pin_memory()
+            buf = torch.empty(n, dtype=want, pin_memory=True)
             self.pinned[slot] = buf
-        self.turn = (self.turn + 1) % 3
-        host = buf[:n].view(x.shape)
+        self.turn = (self.turn + 1) % self.kRing
+        host = buf[:n].view(tuple(x.shape))
         dst = host.numpy()
-        if self.pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self.pool = ThreadPoolExecutor(self.kCopyThreads)
+        x = np.asarray(x)
         rows = x.shape[0]
-        step = (rows + self.kCopyThreads - 1) // self.kCopyThreads
-        list(self.pool.map(lambda r0: np.copyto(dst[r0:r0 + step], x[r0:r0 + step]), range(0, rows, step)))
+        step = (rows + self.kReaders - 1) // self.kReaders
+        list(self._pool().map(lambda r0: np.copyto(dst[r0:r0 + step], x[r0:r0 + step]), range(0, rows, step)))
         return host, slot
 
     def to_device(self, staged):
@@ -79,11 +99,12 @@ class _Stager(object):
             dev = host.to(self.device, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
-        self.ready[slot] = ready
+        if slot is not None:
+            self.ready[slot] = ready
         compute.wait_event(ready)
         dev.record_stream(compute)
         if dev.dtype == torch.int16:
-            dev = (dev.to(torch.float64) / 32767.0).to(torch.float32)
+            dev = pcm16_to_float32(dev)
         return dev
 
     def plain(self, x):
@@ -93,7 +114,30 @@ class _Stager(object):
         return move_data_to_device(x, self.device)
 
 
-def _ahead(generator, prepare, depth=1):
+def pcm16_to_float32(dev_int16):
+    """int16 device tensor -> float32 by the library's kernel (include/acx.h: acx_pcm16_to_f32), on the current stream."""
+    from .. import _ffi
+    out = torch.empty(dev_int16.shape, dtype=torch.float32, device=dev_int16.device)
+    _ffi.check(_ffi.lib().acx_pcm16_to_f32(_ffi.ptr(dev_int16), _ffi.ptr(out), dev_int16.numel(), _ffi.stream_ptr(dev_int16.device)))
+    return out
+
+
+_STAGERS = {}
+
+
+def stager_for(device):
+    """The process-wide stager of `device`: its pinned ring is allocated once (pinning 4 x 164 MB costs tens of milliseconds --
+    a sweep of a few batches would spend a third of its time there if every forward() made its own)."""
+    import threading
+    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0),
+           threading.get_ident())       # (a sweep per thread: two concurrent sweeps never share a ring)
+    st = _STAGERS.get(key)
+    if st is None:
+        st = _STAGERS[key] = _Stager(device)
+    return st
+
+
+def _ahead(generator, prepare, depth=2):
     """Runs `generator` (and `prepare` on each item) in a background thread, `depth` batches ahead: reading the clips
     (memory-mapped shards), any host-side conversion and the copy into pinned memory overlap the GPU's work on the previous
     batch.  Exceptions re-raise in the consumer."""
@@ -138,12 +182,12 @@ def _ahead(generator, prepare, depth=1):
 
 def forward(model, generator, return_input=False, return_target=False):
     """Forward data to a model in mini-batches (pytorch_utils.py:63-137).  Same results in the same order; the batches are
-    read and staged into pinned memory one ahead in a background thread, copied to the device on a side stream, and the
+    read and staged into pinned memory two ahead in a background thread, copied to the device on a side stream, and the
     outputs of batch i are fetched only after batch i + 1 has been handed to the GPU: host work, PCIe and the model overlap."""
     output = {}
     device = next(model.parameters()).device
     model.eval()
-    stage = _Stager(device)
+    stage = stager_for(device)
 
     def append(key, value):
         output.setdefault(key, []).append(value)

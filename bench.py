@@ -60,11 +60,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_COPY_GBS = 6290.0          # the same guide: what a float4 copy reaches on this part (79 %); SURVEY 8(d) asks for both
 MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA, dense (no xf32 on gfx950)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA at the nominal 2.4 GHz
-# Shader clock the chip holds inside the split-fp16 MFMA kernels under load: 1.69 GHz stamped with s_memtime / s_memrealtime
-# in round 1's diagnostic builds (32x32x16 MFMAs), 1.94-2.11 GHz by GRBM_GUI_ACTIVE / duration in round 3's PMC passes of the
-# 16x16x32 kernels (profiles/r03_x_split_pmc_per_kernel.csv, r03_q_*: it differs box to box and falls as the loop gets tighter).
-# Reported next to `frac` as extra information; `peak` and `frac` themselves stay on the nominal 2.4 GHz figure.
-SPLIT_SHADER_CLOCK_GHZ = 1.95
 DIMS, DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
 
 
@@ -142,13 +137,18 @@ def algorithmic_work(B, L, precision="fp32"):
     return work
 
 
-def measured_traffic(precision="fp32_split"):
-    """HBM bytes per launch per kernel class from the newest committed rocprofv3 PMC summary of THIS arithmetic under
-    profiles/ (tools/pmc_table.py: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes).  PMC counters cannot be read from
-    inside this process, so `traffic` is the profiled figure of the same workload, not a live measurement."""
+def measured_traffic(precision="fp32_split", workload="bs64"):
+    """HBM bytes per launch per kernel class from the newest committed rocprofv3 PMC summary of THIS arithmetic and workload
+    ("bs64": one forward of 64 x 10 s; "frame256": forward_frame_embeddings at bs = 256) under profiles/ (tools/pmc_table.py:
+    FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes).  PMC counters cannot be read from inside this process, so `traffic`
+    is the profiled figure of the same workload, not a live measurement; the same files carry the shader clock
+    (GRBM_GUI_ACTIVE / duration) the kernels of a class ran at in that pass."""
     import glob
     tag = {"fp32_split": "split", "bf16a": "bf16a", "bf16": "bf16", "fp32": "fp32"}[precision]
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % tag)))
+    if workload != "bs64":
+        tag += "_" + workload
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % tag))
+                   if workload != "bs64" or "_frame256_" not in os.path.basename(f))
     if not files:
         return {}, None
     try:
@@ -337,8 +337,10 @@ def profile_rooflines(model, dev, fn, B, precision, n_prof, L=CLIP_SAMPLES):
     per_launch_flops = g["flops"] / g["launches"]
     avg_launch_s = g["ms"] * 1e-3 / g["launches"]
     ach = per_launch_flops / avg_launch_s / 1e12
-    traffic, traffic_src = measured_traffic(precision)
-    tr = lambda k: (traffic.get(k, {}).get("hbm_traffic_bytes_per_launch") if (B == 64 and L == CLIP_SAMPLES) else None)
+    # counter traffic exists for the two workloads the PMC passes ran: 64 x 10 s (any output) and frame embeddings at bs = 256
+    wl = "bs64" if (B == 64 and L == CLIP_SAMPLES) else ("frame256" if (B == 256 and L == CLIP_SAMPLES) else None)
+    traffic, traffic_src = measured_traffic(precision, wl) if wl else ({}, None)
+    tr = lambda k: traffic.get(k, {}).get("hbm_traffic_bytes_per_launch")
     dom_classes = [k for k in groups[dom] if k in kernels]
     tr_dom = [tr(k) for k in dom_classes]
     tr_dom = (sum(t * kernels[k]["launches_per_step"] for t, k in zip(tr_dom, dom_classes)) / g["launches"]
@@ -353,10 +355,13 @@ def profile_rooflines(model, dev, fn, B, precision, n_prof, L=CLIP_SAMPLES):
                        "algorithmic_flops_per_launch": per_launch_flops,
                        "executed_mfma_flops_per_launch": mfma_mult * per_launch_flops,
                        "algorithmic_bytes_per_launch": g["bytes"] / g["launches"]}
-    if split:
-        pk = 1024 * 1024 * SPLIT_SHADER_CLOCK_GHZ / 1e3 / 3.0     # SIMDs x flop/cycle/SIMD x GHz / 3 -> TFLOP/s algorithmic
-        out["roofline"].update({"shader_clock_GHz_in_kernel_pmc": SPLIT_SHADER_CLOCK_GHZ,
-                                "peak_at_that_clock": pk, "frac_at_that_clock": ach / pk})
+    # the shader clock this kernel class held in the PMC pass of the same workload (GRBM_GUI_ACTIVE / 8 XCDs / duration, from
+    # the traffic file -- a measurement of that run, not a constant): the matrix peak at THAT clock, beside the nominal one
+    clocks = [traffic.get(k, {}).get("shader_clock_GHz") for k in dom_classes]
+    if clocks and all(c is not None for c in clocks):
+        ghz = sum(c * kernels[k]["ms_per_step"] for c, k in zip(clocks, dom_classes)) / sum(kernels[k]["ms_per_step"] for k in dom_classes)
+        pk = raw_peak * ghz / 2.4 / mfma_mult
+        out["roofline"].update({"shader_clock_GHz_in_pmc_pass": ghz, "peak_at_that_clock": pk, "frac_at_that_clock": ach / pk})
     if bf16:        # at bf16 rates a kernel may be bound by its HBM traffic, not the matrix pipe: report the binding one, keep both
         gbs = g["bytes"] / g["launches"] / avg_launch_s / 1e9
         out["roofline"].update({"mfma_tflops": ach, "mfma_frac": ach / peak, "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
@@ -545,6 +550,10 @@ def main():
         dt = time.perf_counter() - t0
         line["native_f32_mfma"] = {"value": B * n_nat / dt, "unit": "clips/s", "ms_per_step": 1e3 * dt / n_nat, "steps": n_nat,
                                    "note": "v_mfma_f32_32x32x2_f32 path (--precision fp32), same workload and process"}
+        # the strict-fp32 arithmetic gets the same per-kernel objects (peak: the dense f32-input MFMA rate, 157.3 TFLOP/s)
+        nat = profile_rooflines(model, dev, fn, B, "fp32", 2)
+        line["native_f32_mfma"].update({k: nat[k] for k in ("roofline", "roofline_other_matrix_kernels", "roofline_all_pointwise", "roofline_dwconv")})
+        line["native_f32_mfma"]["kernels"] = {k: {"ms_per_step": v["ms_per_step"], "launches_per_step": v["launches_per_step"]} for k, v in nat["kernels"].items()}
         model.set_precision("fp32_split")
     if rank == 0 and world == 1 and split and not args.no_profile and not args.no_extra_configs and args.mode == "logits" and B == 64:
         # The other single-GPU BASELINE configs, measured in this process next to the headline:
@@ -572,6 +581,26 @@ def main():
         sub["kernels"] = {k: {"ms_per_step": v["ms_per_step"], "launches_per_step": v["launches_per_step"]} for k, v in pr["kernels"].items()}
         line["frame_bs256"] = sub
         del wav2
+        # configs[4]'s per-rank workload, PCIe included (never `value`): 2 048 int16 clips in pageable host memory, batches of 256
+        # through pytorch/evaluate.py::forward as evaluate_sharded drives it (staging into the pinned ring two batches ahead,
+        # int16 over PCIe on a copy stream, widening on the GPU, scores fetched one batch behind)
+        import numpy as np
+        from audioset_convnext_inf_amd.pytorch import evaluate as ev
+        from audioset_convnext_inf_amd.utils.data_generator import ClipShard, evaluate_batches
+        n_sw = 2048
+        g = np.random.Generator(np.random.PCG64(11))
+        shard = ClipShard(g.integers(-3277, 3277, size=(n_sw, CLIP_SAMPLES), dtype=np.int16), np.zeros((n_sw, 527), np.bool_))
+        ev.forward(model, evaluate_batches(shard, batch_size=256, device_cast=True))          # pins the ring once per process
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        sc = ev.forward(model, evaluate_batches(shard, batch_size=256, device_cast=True))["clipwise_output"]
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        line["eval_sweep"] = {"value": n_sw / dt, "unit": "clips/s", "clips": n_sw, "batch": 256, "seconds": dt,
+                              "vs_resident_bs256": (n_sw / dt) / line["frame_bs256"]["value"], "scores_shape": list(sc.shape),
+                              "workload": "BASELINE configs[4] per-rank: int16 clips in pageable host memory -> pinned ring -> PCIe -> "
+                                          "acx_pcm16_to_f32 -> forward -> scores on the host (pytorch/evaluate.py::forward); PCIe-inclusive"}
+        del shard
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     if rank == 0:

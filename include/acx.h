@@ -188,6 +188,12 @@ ACX_API int acx_pool_head(acx_ctx* ctx, const float* x, int B, int H3, float* sc
 /* NHWC -> NCHW (the layout forward_frame_embeddings returns, convnext.py:276-277). */
 ACX_API int acx_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, void* stream);
 
+/* Stored clips -> model input, on the device: out[i] = float(double(pcm[i]) / 32767.0), the arithmetic (and therefore the
+ * bits) of the reference's host-side `int16_to_float32` (utils/utilities.py:226-227; applied by the AudioSet dataset,
+ * utils/data_generator.py:72).  The evaluation sweep copies the int16 clips over PCIe (half the bytes) and widens them here,
+ * in stream order in front of acx_forward.  Both buffers on the device, 16-byte aligned; n samples. */
+ACX_API int acx_pcm16_to_f32(const int16_t* pcm, float* out, int64_t n, void* stream);
+
 /* How acx_finalize decided to evaluate the frontend: *dense_dft = 0 when the stored STFT buffers are window x DFT (max
  * deviation *stft_deviation <= 2e-6) and the FFT kernel stands in for the two Conv1d, 1 when they are not and the
  * contraction runs as stored (GEMM on the f32 matrix cores) -- the reference applies whatever its state_dict holds
@@ -199,6 +205,10 @@ ACX_API int acx_frontend_info(const acx_ctx* ctx, int* dense_dft, float* stft_de
  * environment once, at the first acx_create; this re-reads them (tests force every tile shape through it and require
  * bit-identical results).  Launches never touch the environment.  No reference counterpart. */
 ACX_API int acx_tuning_refresh(void);
+/* Test support: make acx_forward report ACX_ERR_STATE after it has queued sub-batch `sub` (0 .. 3) of a split batch, so that
+ * the error path -- joining the forked streams, ending a capture cleanly -- can be exercised; -1 switches it off (the default).
+ * A call, not an environment variable: nothing in a production environment can arm it.  No reference counterpart. */
+ACX_API int acx_test_fail_sub(int sub);
 
 /* ---- measurement: per-kernel-class device time, HIP events on the launch stream ------------ */
 ACX_API int acx_profile_enable(acx_ctx* ctx, int on);

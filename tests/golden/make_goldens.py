@@ -244,6 +244,14 @@ def main():
         g3["7359"] = "RuntimeError: " + str(e).split("\n")[0][:120]
     manifest["shapes"]["g3_lengths"] = g3
 
+    # deviations measured on an MI355X per parity case (tests/parity_floor.py) live in the same file: keep them
+    try:
+        with open(os.path.join(HERE, "MANIFEST.json")) as f:
+            kept = json.load(f).get("measured_on_mi355x")
+        if kept:
+            manifest["measured_on_mi355x"] = kept
+    except (OSError, ValueError):
+        pass
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("wrote goldens to", HERE)

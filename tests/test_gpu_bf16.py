@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from audioset_convnext_inf_amd import _ffi
 from audioset_convnext_inf_amd.pytorch.convnext import convnext_tiny
+import parity_floor
 
 pytestmark = pytest.mark.gpu
 
@@ -145,7 +146,9 @@ def test_e2e_bf16_drift_on_demo_clip(model16, golden_dir):
     d_prob = maxdiff(out["clipwise_output"], torch.from_numpy(g["probs"]))
     d_scene = maxdiff(model16.forward_scene_embeddings(wav), torch.from_numpy(g["scene"]))
     print("bf16 e2e drift: logits %.3g probs %.3g scene %.3g" % (d_logit, d_prob, d_scene))
-    assert d_logit < DRIFT_E2E_TOL and d_prob < 0.05 and d_scene < DRIFT_E2E_TOL
+    # contract: the drift bf16 operands allow through 18 blocks; regression bar: 3 x the drift recorded for these rounding points
+    parity_floor.check("bf16/g1_demo_drift/" + model16.precision, {"logits": d_logit, "probs": d_prob, "scene": d_scene},
+                       {"logits": DRIFT_E2E_TOL, "probs": 0.05, "scene": DRIFT_E2E_TOL}, factor=3.0)
     ref_dec = g["probs"][0] > 0.25
     got_dec = out["clipwise_output"][0].cpu().numpy() > 0.25
     if model16.precision == "bf16":

@@ -136,3 +136,28 @@ def test_evaluate_script_synthetic_sweep(model, synth_sd):
     w4 = torch.from_numpy((shard.waveforms[:3] / 32767.0).astype(np.float32))
     ref = ref_cpu.forward(synth_sd, w4)["clipwise_output"]
     assert float((torch.from_numpy(scores[:3]) - ref).abs().max()) < 1e-3
+
+
+def test_pcm16_to_f32_is_the_reference_arithmetic():
+    """acx_pcm16_to_f32 (include/acx.h) against utilities.int16_to_float32 -- (x / 32767.0).astype(float32), the reference's
+    utils/utilities.py:226-227 -- on every int16 value, bit for bit, and on a buffer whose length is not a multiple of 8."""
+    import ctypes
+    import numpy as np
+    import torch
+    from audioset_convnext_inf_amd import _ffi
+    from audioset_convnext_inf_amd.utils.utilities import int16_to_float32
+    allv = np.arange(-32768, 32768, dtype=np.int16)
+    x = np.concatenate([allv, allv[::-1], allv[:12345]])
+    assert x.size % 8 != 0
+    dev = torch.from_numpy(x).cuda()
+    out = torch.empty(x.size, dtype=torch.float32, device="cuda")
+    _ffi.check(_ffi.lib().acx_pcm16_to_f32(_ffi.ptr(dev), _ffi.ptr(out), x.size, _ffi.stream_ptr(dev.device)))
+    torch.cuda.synchronize()
+    want = int16_to_float32(x)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # through the evaluation harness' own helper (what pytorch/evaluate.py::forward calls)
+    from audioset_convnext_inf_amd.pytorch.evaluate import pcm16_to_float32
+    got = pcm16_to_float32(dev.view(3, -1)[:, :40000].contiguous())
+    assert np.array_equal(got.cpu().numpy(), int16_to_float32(x.reshape(3, -1)[:, :40000]))
+    rc = _ffi.lib().acx_pcm16_to_f32(ctypes.c_void_p(dev.data_ptr() + 2), _ffi.ptr(out), 8, _ffi.stream_ptr(dev.device))
+    assert rc != 0 and b"aligned" in _ffi.lib().acx_last_error()

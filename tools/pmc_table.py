@@ -2,7 +2,9 @@
 """Merge three rocprofv3 --pmc passes (SQ+GRBM | FETCH_SIZE | WRITE_SIZE) of tools/prof_step.py into one
 per-kernel table and a per-kernel-class traffic summary (HBM bytes per launch, FETCH_SIZE doubled as
 MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950).
-usage: pmc_table.py <dir_sq> <dir_fetch> <dir_write> <out_csv> <out_json> [precision label]"""
+usage: pmc_table.py <dir_sq> <dir_fetch> <dir_write> <out_csv> <out_json> [precision label] [workload label]
+Per class the JSON also carries the shader clock the kernels of that class ran at (GRBM_GUI_ACTIVE / 8 XCDs / duration).
+"""
 import collections, csv, glob, json, sys
 
 def load(d):
@@ -31,10 +33,11 @@ def cls(name):
     return None
 
 PREC = sys.argv[6] if len(sys.argv) > 6 else "fp32_split"
+WORK = sys.argv[7] if len(sys.argv) > 7 else "one forward, B=64, 10 s @ 32 kHz"
 sq, fe, wr = load(sys.argv[1]), load(sys.argv[2]), load(sys.argv[3])
 agg = collections.OrderedDict()
 with open(sys.argv[4], "w") as out:
-    out.write("# one forward, B=64 x 10 s (tools/prof_step.py --precision %s, one stream); three separate rocprofv3 --pmc passes.\n" % PREC)
+    out.write("# %s (tools/prof_step.py --precision %s, one stream); three separate rocprofv3 --pmc passes.\n" % (WORK, PREC))
     out.write("# fetch_MB_x2 = 2 * FETCH_SIZE (gfx950 reports half the bytes of 16 B/lane streaming reads); write_MB = WRITE_SIZE.\n")
     out.write("class,kernel,grid,dur_us,clock_GHz,waves_per_SIMD,wait_any,wait_inst_any,valu_active,mfma_util,lds_bank_conflict_per_cu_cycle,fetch_MB_x2,write_MB\n")
     for x, y, z in zip(sq, fe, wr):
@@ -48,12 +51,13 @@ with open(sys.argv[4], "w") as out:
             c, x["name"][:70], x["grid"], x["dt"], gui / x["dt"] / 1e3, x["SQ_WAVE_CYCLES"] * 4 / (gui * 1024),
             x["SQ_WAIT_ANY"] / x["SQ_WAVE_CYCLES"], x["SQ_WAIT_INST_ANY"] / x["SQ_WAVE_CYCLES"],
             x["SQ_ACTIVE_INST_VALU"] / x["SQ_WAVE_CYCLES"], mf, x["SQ_LDS_BANK_CONFLICT"] / (gui * 256), fetch, write))
-        a = agg.setdefault(c, {"launches": 0, "fetch_MB_x2": 0.0, "write_MB": 0.0, "mfma_busy": 0.0, "simd_cycles": 0.0})
+        a = agg.setdefault(c, {"launches": 0, "fetch_MB_x2": 0.0, "write_MB": 0.0, "mfma_busy": 0.0, "simd_cycles": 0.0, "gui": 0.0, "dt_us": 0.0})
+        a["gui"] += gui; a["dt_us"] += x["dt"]
         a["launches"] += 1; a["fetch_MB_x2"] += fetch; a["write_MB"] += write
         a["mfma_busy"] += x.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0); a["simd_cycles"] += gui * 1024
 summary = {c: {"launches_per_step": a["launches"], "hbm_traffic_bytes_per_launch": (a["fetch_MB_x2"] + a["write_MB"]) * 1e6 / a["launches"],
                "fetch_bytes_per_launch_x2": a["fetch_MB_x2"] * 1e6 / a["launches"], "write_bytes_per_launch": a["write_MB"] * 1e6 / a["launches"],
-               "mfma_util_cycles": a["mfma_busy"] / a["simd_cycles"]} for c, a in agg.items()}
+               "mfma_util_cycles": a["mfma_busy"] / a["simd_cycles"], "shader_clock_GHz": a["gui"] / a["dt_us"] / 1e3} for c, a in agg.items()}
 json.dump({"source": "rocprofv3 --pmc, 3 passes: SQ_*+GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE; FETCH_SIZE x2 (gfx950 correction)",
-           "workload": "one forward, B=64, 10 s @ 32 kHz (tools/prof_step.py --precision %s, one stream)" % PREC, "classes": summary}, open(sys.argv[5], "w"), indent=1)
+           "workload": "%s (tools/prof_step.py --precision %s, one stream)" % (WORK, PREC), "classes": summary}, open(sys.argv[5], "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -12,5 +12,9 @@ for pair in fp32_split:split bf16a:bf16a bf16:bf16 fp32:fp32; do
   cp $(ls -t $(find $O/stats_onestream -name "*kernel_stats.csv") | head -1) profiles/${TAG}_${N}_onestream_kernel_stats.csv
   cp $O/pmc_per_kernel.csv profiles/${TAG}_${N}_pmc_per_kernel.csv
   cp $O/traffic.json profiles/${TAG}_${N}_traffic.json
+  if [ -f $O/frame256_traffic.json ]; then
+    cp $O/frame256_traffic.json profiles/${TAG}_${N}_frame256_traffic.json
+    cp $O/frame256_pmc_per_kernel.csv profiles/${TAG}_${N}_frame256_pmc_per_kernel.csv
+  fi
   echo "stashed $P -> profiles/${TAG}_${N}_*"
 done
