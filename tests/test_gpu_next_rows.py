@@ -157,7 +157,7 @@ def test_pcm16_to_f32_is_the_reference_arithmetic():
     assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
     # through the evaluation harness' own helper (what pytorch/evaluate.py::forward calls)
     from audioset_convnext_inf_amd.pytorch.evaluate import pcm16_to_float32
-    got = pcm16_to_float32(dev.view(3, -1)[:, :40000].contiguous())
-    assert np.array_equal(got.cpu().numpy(), int16_to_float32(x.reshape(3, -1)[:, :40000]))
+    got = pcm16_to_float32(dev[:3 * 47805].view(3, -1)[:, :40000].contiguous())
+    assert np.array_equal(got.cpu().numpy(), int16_to_float32(x[:3 * 47805].reshape(3, -1)[:, :40000]))
     rc = _ffi.lib().acx_pcm16_to_f32(ctypes.c_void_p(dev.data_ptr() + 2), _ffi.ptr(out), 8, _ffi.stream_ptr(dev.device))
     assert rc != 0 and b"aligned" in _ffi.lib().acx_last_error()
