@@ -299,13 +299,40 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     // (not for LNOUT at C = 384: its epilogue needs every accumulator AND every residual value at once for the LayerNorm
     // statistics -- 288 + working registers: hipcc spilled 640 B per lane around the last segments; the residual of that
     // variant is read in the epilogue instead, tile by tile, from rows the previous block left in the cache)
-    constexpr bool kPrefetchX = !(LNOUT && C >= 384);
-    float4 xr[PT][kPrefetchX ? C / 8 : 1];
+    // kXM: the residual through the matrix pipe (below) -- where it measured faster: C = 192 (two pixel tiles per wave: 205 -> 198 us
+    // per block in the lab, profiles/r05_c_ring_residual_ab.txt; C = 384: 170 -> 174, hipcc spills fragments that are in flight
+    // during the last segments; C = 96: no change)
+    constexpr bool kXM = ABF && C == 192;
+    constexpr bool kPrefetchX = !(LNOUT && C >= 384) || kXM;
+    // bf16 rows (ABF, round 5): the residual enters through the matrix pipe -- out += I . x with x read as B fragments (lane
+    // (px, hh): channels 16 u + 8 hh .. + 7, ONE 16-byte load) and I the identity as an A fragment: 1.0 x bf16 is exact in the fp32
+    // accumulate, two MFMAs per out tile.  In the accumulator layout the rows were 48 eight-byte loads per pixel tile, and a
+    // load's address processing costs 4 cycles per LANE whatever its width (tools/lab/pair_lab.hip stamps: 47 k cycles of the
+    // CU's one texture-address path per 128-pixel tile, the path the LDS-DMA weight pieces queue on) -- now 24 sixteen-byte
+    // loads into half the registers (C/4 per pixel tile instead of C/2).
+    float4 xr[PT][(kPrefetchX && !kXM) ? C / 8 : 1];
+    f32x4 xf[PT][kXM ? C / 16 : 1];
+    constexpr int kEarlyX = kXM ? C / 16 : 0;
+    f32x4 ident[2];
+    if constexpr (kXM) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const int e = l31 - 16 * sp - 8 * hh;             // this lane's row of I has its 1 at k = 16 s' + 8 hh + e
+            unsigned w[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) w[p] = (e == 2 * p ? 0x3f80u : 0u) | (e == 2 * p + 1 ? 0x3f800000u : 0u);
+            ident[sp] = __builtin_bit_cast(f32x4, uint4{w[0], w[1], w[2], w[3]});
+        }
+    }
     // C = 384: requested one segment later, once the pre-activation tiles of the last GELU are dead (two segments ahead
     // hipcc spilled 156 B per lane around here)
     constexpr bool kLateX = C >= 384;
 #define ACX_LOAD_XR()                                                                                           \
-    if constexpr (kPrefetchX) {                                                                                 \
+    if constexpr (kXM) {                                                                                        \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)                                                       \
+        _Pragma("unroll") for (int u = 0; u < kEarlyX; ++u)                                                     \
+            xf[pt][u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(x) + mrow[pt] * C + 8 * hh + 16 * u); \
+    } else if constexpr (kPrefetchX) {                                                                          \
         _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)                                                       \
         _Pragma("unroll") for (int t = 0; t < Cfg::kTiles; ++t)                                                 \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) xr[pt][4 * t + q] = acx_ld4<ABF>(x, mrow[pt] * C + 4 * hh + 32 * t + 8 * q); \
@@ -335,6 +362,16 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     // ---- epilogue: lane (px, hh), tile t, q: channels 32t + 8q + 4hh .. +3  ->  x = x + out + b2 ---------
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
+        if constexpr (kXM) {        // out += I . x
+#pragma unroll
+            for (int u = kEarlyX; u < C / 16; ++u)
+                xf[pt][u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(x) + mrow[pt] * C + 8 * hh + 16 * u);
+#pragma unroll
+            for (int t = 0; t < Cfg::kTiles; ++t)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+                    acc[pt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ident[sp]), __builtin_bit_cast(bf16x8, xf[pt][2 * t + sp]), acc[pt][t], 0, 0, 0);
+        }
         if constexpr (LNOUT) {
             // last block of the stage in the full forward: the only reader of the new x is the LayerNorm in front of the
             // downsample conv (convnext.py:230-235): write that GEMM's bf16 operand rows instead of x
@@ -345,7 +382,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
                 for (int q = 0; q < 4; ++q) {
                     const float4 bb = *reinterpret_cast<const float4*>(b2s + 32 * t + 8 * q + 4 * hh);
                     float4 v;
-                    if constexpr (kPrefetchX) v = xr[pt][4 * t + q];
+                    if constexpr (kXM) v = make_float4(0.f, 0.f, 0.f, 0.f);         // (already in acc)
+                    else if constexpr (kPrefetchX) v = xr[pt][4 * t + q];
                     else v = acx_ld4<ABF>(x, mrow[pt] * C + 4 * hh + 32 * t + 8 * q);
                     acc[pt][t][4 * q + 0] += v.x + bb.x; acc[pt][t][4 * q + 1] += v.y + bb.y;
                     acc[pt][t][4 * q + 2] += v.z + bb.z; acc[pt][t][4 * q + 3] += v.w + bb.w;
@@ -394,7 +432,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
                     for (int i = 0; i < 2; ++i) {
                         const int q = 2 * j + i;
                         const float4 bb = *reinterpret_cast<const float4*>(b2s + 32 * t + 8 * q + 4 * hh);
-                        v[i] = xr[pt][4 * t + q];
+                        if constexpr (kXM) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);          // (already in acc)
+                        else v[i] = xr[pt][4 * t + q];
                         v[i].x += acc[pt][t][4 * q + 0] + bb.x;
                         v[i].y += acc[pt][t][4 * q + 1] + bb.y;
                         v[i].z += acc[pt][t][4 * q + 2] + bb.z;

@@ -155,6 +155,11 @@ __global__ __launch_bounds__(512) void mlp_pair_bf16_kernel(
 #else
 #define ACX_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
 #endif
+#ifdef ACX_PAIR_TRIPLE      // (lab: what would three MFMAs per fragment -- the fp32_split arithmetic -- make of this skeleton? timing only)
+#define ACX_MFMA3(a_, b_, c_) ACX_MFMA(a_, b_, ACX_MFMA(a_, b_, ACX_MFMA(a_, b_, c_)))
+#else
+#define ACX_MFMA3(a_, b_, c_) ACX_MFMA(a_, b_, c_)
+#endif
 
     if (wave < 4) {
         // ================================ producer ================================
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(512) void mlp_pair_bf16_kernel(
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt)
-                    Xn[pt] = ACX_MFMA(ACX_B8(f[sx % kD]), ACX_B8(act[pt][sx]), Xn[pt]);
+                    Xn[pt] = ACX_MFMA3(ACX_B8(f[sx % kD]), ACX_B8(act[pt][sx]), Xn[pt]);
                 if constexpr (sx < kSpan) {
 #pragma unroll
                     for (int i = sx * kCnt / kSpan; i < (sx + 1) * kCnt / kSpan; ++i) dma_piece(i, rq0, rq1);
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(512) void mlp_pair_bf16_kernel(
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt)
-                    acc[pt][u >> 1] = ACX_MFMA(ACX_B8(f[u % kD]), ACX_B8(g[pt][u & 1]), acc[pt][u >> 1]);
+                    acc[pt][u >> 1] = ACX_MFMA3(ACX_B8(f[u % kD]), ACX_B8(g[pt][u & 1]), acc[pt][u >> 1]);
                 // pieces [u kCnt / kSpan, (u + 1) kCnt / kSpan) ride behind unit u
 #pragma unroll
                 for (int i = (u < kSpan ? u * kCnt / kSpan : kCnt); i < (u + 1 < kSpan ? (u + 1) * kCnt / kSpan : kCnt) && u < kSpan; ++i)
@@ -560,6 +565,7 @@ __global__ __launch_bounds__(512) void mlp_pair_bf16_kernel(
     }
 #undef ACX_B8
 #undef ACX_MFMA
+#undef ACX_MFMA3
 #undef ACX_ENDINT
 }
 
