@@ -127,7 +127,6 @@ struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layou
     uint16_t* wpack_s = nullptr; // split mode, C = 96/192: chunk-major [W1c | W2c] S16 image (mlp_fused_split.hip)
     uint16_t* wstream_b = nullptr; // bf16 mode: the same segment stream in bf16, chunks of 64 hidden units (mlp_fused_wide_bf16.hip)
     uint16_t* wstream_p = nullptr; // bf16 modes, C = 192 / 384: 32-hidden-unit segments in the consumption order of mlp_pair_bf16.hip
-    uint16_t* wstream_ps = nullptr; // split mode, C = 96 / 192: 32-hidden-unit S16 segments in the consumption order of mlp_pair_split.hip
     uint16_t* wstream_s = nullptr; // split mode, C = 384: segment stream in consumption order, LDS image order (mlp_fused_wide.hip)
     float w1s_scale = 1.f, w2s_scale = 1.f;
     float hid_scale = 1.f;   // split mode: power-of-two scale of the S16 hidden activation (GELU output)
@@ -229,7 +228,6 @@ struct Tuning {
     std::atomic<int> fail_sub{-1};     // acx_test_fail_sub(i): acx_forward reports a failure after queueing sub-batch i (error-path tests; never read from the environment)
     std::atomic<int> wide_pers{0};     // ACX_WIDE_PERSIST: 1 = persistent wide fused MLP wherever it exists, 2 = never; 0 = by launch size
     std::atomic<int> bf16_pair{-1};    // ACX_BF16_PAIR = 1: the paired (producer / consumer) fused bf16 MLP instead of the ring kernels (C = 192, 384); default: ring
-    std::atomic<int> split_pair{-1};   // ACX_SPLIT_PAIR = 0 | 1: the one-wave-per-SIMD (0) / paired (1) fused fp32_split MLP of stages 0-1 (-1: the default)
     std::atomic<int> dw_stream{-1};    // ACX_DW_STREAM = 0 | 1: forces the tile / column-streaming depthwise kernels (-1: by launch size)
 };
 Tuning& tuning();
@@ -337,11 +335,6 @@ int mlp_pair_bf16_pos_w1(int C, int k);
 int mlp_pair_bf16_pos_w2(int C, int j);
 int launch_mlp_pair_bf16(acx_ctx* c, const BlockW& w, int C, const void* y, void* x, long long M, hipStream_t s,
                          void* ln_out, int ld_out, bool act_bf16);
-bool mlp_pair_split_supported(int C);         // mlp_pair_split.hip: producer / consumer wave pairs in fp32_split arithmetic (C = 96, 192)
-int mlp_pair_split_swz(int C, int row);
-int mlp_pair_split_pos_w1(int C, int k);
-int mlp_pair_split_pos_w2(int C, int j);
-int launch_mlp_pair_split(acx_ctx* c, const BlockW& w, int C, const float* y, float* x, long long M, hipStream_t s, void* ln_out);
 bool mlp_fused_wide_bf16_supported(int C);
 int mlp_fused_wide_bf16_swz(int C, int row);
 int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const void* y, void* x, long long M, hipStream_t s,

@@ -29,7 +29,6 @@ void tuning_reload() {
     t.gemm_32x32.store(digit("ACX_GEMM_32X32", "1", 0), std::memory_order_relaxed);
     t.dw_stream.store(digit("ACX_DW_STREAM", "01", -1), std::memory_order_relaxed);
     t.bf16_pair.store(digit("ACX_BF16_PAIR", "01", -1), std::memory_order_relaxed);
-    t.split_pair.store(digit("ACX_SPLIT_PAIR", "012", -1), std::memory_order_relaxed);
 }
 
 void set_error(const char* fmt, ...) {
@@ -434,43 +433,6 @@ static int finalize_impl(acx_ctx* c) {
                 const std::vector<uint16_t> h1 = s16_rows(f1, 4 * C, C, bw.w1s_scale);
                 ACX_TRY(upload(c, h1, &bw.w1s));
                 ACX_TRY(upload(c, s16_rows(f2, C, 4 * C, bw.w2s_scale), &bw.w2s));
-                if (c->use_fused_mlp && mlp_pair_split_supported(C)) {
-                    // mlp_pair_split.hip: S16 segments of 32 hidden units (128 C bytes each) at the stream positions the kernel consumes
-                    // them in (W1(k) in interval k, W2(j) in interval j + 2), each in LDS image order: a value's hi half in chunk 2b,
-                    // its lo half in chunk 2b + 1 of its row (b = block of 8 k values), chunks XOR-swizzled per row
-                    const int nch = 4 * C / 32;
-                    const size_t seg = (size_t)64 * C;                   // uint16 elements per segment
-                    std::vector<uint16_t> st((size_t)2 * nch * seg);
-                    for (int k = 0; k < nch; ++k) {
-                        uint16_t* w1img = st.data() + (size_t)mlp_pair_split_pos_w1(C, k) * seg;
-                        for (int r = 0; r < 32; ++r)
-                            for (int b = 0; b < C / 8; ++b)
-                                for (int e = 0; e < 8; ++e) {
-                                    const float v = f1[(size_t)(32 * k + r) * C + 8 * b + e] * bw.w1s_scale;
-                                    const _Float16 hi = (_Float16)v;
-                                    const _Float16 lo = (_Float16)(v - (float)hi);
-                                    const int sw = mlp_pair_split_swz(C, r);
-                                    std::memcpy(&w1img[(size_t)r * 2 * C + (size_t)((2 * b) ^ sw) * 8 + e], &hi, 2);
-                                    std::memcpy(&w1img[(size_t)r * 2 * C + (size_t)((2 * b + 1) ^ sw) * 8 + e], &lo, 2);
-                                }
-                        // W2 image: row = out channel (128 B = 8 chunks); chunk 4 s' + 2 h + pl (s' = k-step 0..1, pl = 0 hi / 1 lo) holds
-                        // hidden units 32k + 16 s' + 4h + 8(jj >> 2) + (jj & 3) -- the order of the producer's accumulator registers
-                        uint16_t* w2img = st.data() + (size_t)mlp_pair_split_pos_w2(C, k) * seg;
-                        for (int ch = 0; ch < C; ++ch)
-                            for (int sp = 0; sp < 2; ++sp)
-                                for (int h = 0; h < 2; ++h)
-                                    for (int jj = 0; jj < 8; ++jj) {
-                                        const int u = 32 * k + 16 * sp + 4 * h + 8 * (jj >> 2) + (jj & 3);
-                                        const float v = f2[(size_t)ch * 4 * C + u] * bw.w2s_scale;
-                                        const _Float16 hi = (_Float16)v;
-                                        const _Float16 lo = (_Float16)(v - (float)hi);
-                                        const int c0 = 4 * sp + 2 * h, sw = acx_swz8(ch);
-                                        std::memcpy(&w2img[(size_t)ch * 64 + (size_t)(c0 ^ sw) * 8 + jj], &hi, 2);
-                                        std::memcpy(&w2img[(size_t)ch * 64 + (size_t)((c0 + 1) ^ sw) * 8 + jj], &lo, 2);
-                                    }
-                    }
-                    ACX_TRY(upload(c, st, &bw.wstream_ps));
-                }
                 if (mlp_fused_split_supported(C)) {
                     // chunk-major image for mlp_fused_split.hip: per chunk j [W1c = rows 32j..32j+31 of w1s]
                     // [W2c: C rows x 4 blocks; block b = 2s'+h holds hidden units 32j + 16s' + 4h + 8(jj>>2) + (jj&3)]
@@ -638,10 +600,6 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     const int64_t M = (int64_t)B * H * Wd;
     if (c->precision == ACX_PREC_F32_SPLIT) {
         ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st));
-        {   // ACX_SPLIT_PAIR = 1: the paired kernel for stages 0-1, 2: for stage 1 only (mlp_pair_split.hip)
-            const int sp = tuning().split_pair.load(std::memory_order_relaxed);
-            if (c->use_fused_mlp && bw.wstream_ps && (sp == 1 || (sp == 2 && C == 192))) return launch_mlp_pair_split(c, bw, C, y, x, M, st, ln_out);
-        }
         if (c->use_fused_mlp && mlp_fused_wide_supported(C) && bw.wstream_s) return launch_mlp_fused_wide(c, bw, C, y, x, M, st, ln_out);
         if (c->use_fused_mlp && mlp_fused_split_supported(C)) return launch_mlp_fused_split(c, bw, C, y, x, M, st, ln_out);
         if (ln_out) ACX_FAIL(ACX_ERR_STATE, "run_block: LayerNorm output requested from a two-GEMM stage");

@@ -52,6 +52,11 @@ class _Stager(object):
         self.turn = 0
         self.copy_stream = None
         self.pool = None
+        self.dev16 = [None] * self.kRing          # device-side int16 buffers, one per pinned slot
+        self.dev16_read = [None] * self.kRing     # event behind the widening kernel that read it last
+        self.dev32 = [None, None, None]           # float32 batches the model reads, in turn
+        self.turn32 = 0
+        self.fetch_stream = None                  # D2H of the scores, beside the compute stream
 
     def staged(self, x):
         if self.device.type != "cuda":
@@ -93,19 +98,49 @@ class _Stager(object):
     def to_device(self, staged):
         host, slot = staged
         if self.copy_stream is None:
-            self.copy_stream = torch.cuda.Stream(self.device)
+            # a HIGH-PRIORITY stream: HIP multiplexes streams onto a few hardware queues, and on a queue of its priority class the copy
+            # of batch i + 1 sat behind the kernels of forward i (tools/sweep_timeline.py: a 3.1 ms gap between forwards = the copy)
+            self.copy_stream = torch.cuda.Stream(self.device, priority=-1)
         compute = torch.cuda.current_stream(self.device)
+        if host.dtype != torch.int16 or slot is None:
+            with torch.cuda.stream(self.copy_stream):
+                dev = host.to(self.device, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(self.copy_stream)
+            if slot is not None:
+                self.ready[slot] = ready
+            compute.wait_event(ready)
+            dev.record_stream(compute)
+            return pcm16_to_float32(dev) if dev.dtype == torch.int16 else dev
+        # int16 clips: device buffers of the stager's own (one int16 buffer per pinned slot, two float32 buffers the model reads in
+        # turn), allocated once.  Going through the caching allocator instead -- a 164 MB block made on the copy stream and freed on
+        # the compute stream every batch -- cost the sweep 4 ms per batch of 256: the H2D copy did not overlap the model at all
+        # (tools/sweep_timeline.py: 35.4 ms per batch against 31.2 resident, staging 1.9 ms and copy 3.1 ms of their own).
+        n = host.numel()
+        d16 = self.dev16[slot]
+        if d16 is None or d16.numel() < n:
+            with torch.cuda.stream(self.copy_stream):
+                d16 = self.dev16[slot] = torch.empty(n, dtype=torch.int16, device=self.device)
+        t = self.turn32
+        self.turn32 = (t + 1) % len(self.dev32)
+        d32 = self.dev32[t]
+        if d32 is None or d32.numel() < n:
+            d32 = self.dev32[t] = torch.empty(n, dtype=torch.float32, device=self.device)
         with torch.cuda.stream(self.copy_stream):
-            dev = host.to(self.device, non_blocking=True)
+            if self.dev16_read[slot] is not None:           # the widening kernel that last read this buffer
+                self.copy_stream.wait_event(self.dev16_read[slot])
+            d16[:n].copy_(host.view(-1), non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
-        if slot is not None:
-            self.ready[slot] = ready
+        self.ready[slot] = ready
         compute.wait_event(ready)
-        dev.record_stream(compute)
-        if dev.dtype == torch.int16:
-            dev = pcm16_to_float32(dev)
-        return dev
+        out = d32[:n].view(host.shape)
+        from .. import _ffi
+        _ffi.check(_ffi.lib().acx_pcm16_to_f32(_ffi.ptr(d16), _ffi.ptr(out), n, _ffi.stream_ptr(self.device)))
+        done = torch.cuda.Event()
+        done.record(compute)
+        self.dev16_read[slot] = done
+        return out          # (a view of a buffer that comes up again two batches later, in stream order behind this batch's forward)
 
     def plain(self, x):
         x = np.asarray(x)
@@ -192,12 +227,32 @@ def forward(model, generator, return_input=False, return_target=False):
     def append(key, value):
         output.setdefault(key, []).append(value)
 
+    def fetch(t, done):
+        """Device tensor -> numpy WITHOUT going through the compute stream: a `.cpu()` there queues behind the forward of the NEXT
+        batch, which is already on that stream -- the host then runs one batch late and every H2D copy is issued only when the
+        forward it should have overlapped has ended (tools/lab/sweep_copy_trace.py: 3.1 ms per batch of 256).  The copy runs on a
+        side stream behind the event recorded right after the batch's own forward."""
+        if device.type != "cuda":
+            return t.data.cpu().numpy()
+        if stage.fetch_stream is None:
+            stage.fetch_stream = torch.cuda.Stream(device, priority=-1)    # (a queue of its own class: see _Stager.to_device)
+        fs = stage.fetch_stream
+        fs.wait_event(done)
+        with torch.cuda.stream(fs):
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t.data, non_blocking=True)
+            t.record_stream(fs)
+            e = torch.cuda.Event()
+            e.record(fs)
+        e.synchronize()
+        return h.numpy().copy()
+
     def collect(pending):
-        batch, batch_out = pending
-        append("clipwise_output", batch_out["clipwise_output"].data.cpu().numpy())
+        batch, batch_out, done = pending
+        append("clipwise_output", fetch(batch_out["clipwise_output"], done))
         for key in ("segmentwise_output", "framewise_output"):
             if key in batch_out:
-                append(key, batch_out[key].data.cpu().numpy())
+                append(key, fetch(batch_out[key], done))
         if return_input:
             w = batch["waveform"]
             append("waveform", w if np.asarray(w).dtype != np.int16 else (np.asarray(w) / 32767.0).astype(np.float32))
@@ -212,9 +267,13 @@ def forward(model, generator, return_input=False, return_target=False):
         batch_x = stage.to_device(host) if host is not None else stage.plain(batch["waveform"])
         with torch.no_grad():
             batch_out = model(batch_x)
+        done = None
+        if device.type == "cuda":
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(device))
         if pending is not None:
-            collect(pending)                # synchronises with the PREVIOUS batch only
-        pending = (batch, batch_out)
+            collect(pending)                # waits for the PREVIOUS batch only (its own event, a side stream)
+        pending = (batch, batch_out, done)
     if pending is not None:
         collect(pending)
     return {k: np.concatenate(v, axis=0) for k, v in output.items()}
