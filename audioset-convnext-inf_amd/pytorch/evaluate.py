@@ -262,15 +262,25 @@ def forward(model, generator, return_input=False, return_target=False):
     def prepare(batch):                     # reader thread
         return stage.to_pinned(batch["waveform"]) if stage.staged(batch["waveform"]) else None
 
+    def device_input(batch, host):
+        return stage.to_device(host) if host is not None else stage.plain(batch["waveform"])
+
+    # The H2D copy of batch i + 1 is issued as soon as forward i has been queued -- a whole forward before its data is needed -- so
+    # that a copy that lands on a hardware queue behind the library's own sub-batch stream still arrives in time.
     pending = None
-    for batch, host in _ahead(generator, prepare):
-        batch_x = stage.to_device(host) if host is not None else stage.plain(batch["waveform"])
+    it = _ahead(generator, prepare)
+    cur = next(it, None)
+    x_cur = device_input(*cur) if cur is not None else None
+    while cur is not None:
+        batch = cur[0]
         with torch.no_grad():
-            batch_out = model(batch_x)
+            batch_out = model(x_cur)
         done = None
         if device.type == "cuda":
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(device))
+        cur = next(it, None)
+        x_cur = device_input(*cur) if cur is not None else None
         if pending is not None:
             collect(pending)                # waits for the PREVIOUS batch only (its own event, a side stream)
         pending = (batch, batch_out, done)
