@@ -123,7 +123,8 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
     // State: wchunk = byte offset of the chunk block [W1c | W2c] to request next, wdst = LDS address of this wave's first piece
     // in the slot it goes to.  The three pieces of a request differ by 1 KB in LDS (instruction offset -- which also moves the
     // global address, so each piece's per-lane source offset is pre-biased by -1 KB x k) .
-    const char* wsrc[Cfg::kPieces];
+    // (round 5: scalar base + 32-bit lane offset, split_math.h acx_glds16_s -- the per-lane part of a piece's source is the swizzle only)
+    unsigned wsrc[Cfg::kPieces];
 #pragma unroll
     for (int k = 0; k < Cfg::kPieces; ++k) {
         const int idx = (lw * Cfg::kPieces + k) * 64 + lane;           // linear 16-B slot in the LDS image
@@ -131,27 +132,32 @@ __global__ __launch_bounds__(FusedSCfg<C>::kThreads) void mlp_fused_split_kernel
         const int o1 = (r1 * Cfg::kRowChunks + (p1 ^ Cfg::swz1(r1))) * 16;
         const int r2 = idx >> 3, p2 = idx & 7;
         const int o2 = Cfg::kHalfBytes + (r2 * 8 + (p2 ^ ((r2 >> 1) & 7))) * 16;
-        wsrc[k] = wpack + (role == 0 ? o1 : o2);
+        wsrc[k] = (unsigned)(role == 0 ? o1 : o2);
     }
     const unsigned wring_lo = smem_a + (role == 0 ? 0 : kW2Off) + lw * Cfg::kPieces * 1024;
     const unsigned wring_hi = wring_lo + (role == 0 ? R1 : R2) * Cfg::kHalfBytes;
     unsigned wdst = wring_lo;
     unsigned wchunk = 0;
-#define ACX_WREQ_PIECE(k_) acx_glds16_own_m0(wsrc[k_] + wchunk, __builtin_amdgcn_readfirstlane(wdst + (k_) * 1024));
+#define ACX_WREQ_PIECE(k_) acx_glds16_s(wpack + wchunk, wsrc[k_], __builtin_amdgcn_readfirstlane(wdst + (k_) * 1024));
 #define ACX_WREQ_ADVANCE                                                                                        \
         wchunk += 2 * Cfg::kHalfBytes; if (wchunk == (unsigned)n * 2 * Cfg::kHalfBytes) wchunk = 0;             \
         wdst += Cfg::kHalfBytes; if (wdst == wring_hi) wdst = wring_lo;
     // y piece q_ of the tile whose rows start at ynext: lane (px, hh) fetches the 16 bytes it will read back as its q-th chunk:
     // channels 16 (q >> 1) + 8 hh + 4 (q & 1) .. +3 of pixel row tile * kPix + wave * 32 + px (clamped into the tensor)
     const unsigned my_y_a = smem_a + kYOff + wave * (Cfg::kYPieces * 1024);
-    const float* ynext;
+    // (scalar base = the tile's first row, 32-bit lane offset = this lane's row inside the tile: any tensor size)
+    const float* ynext;       // wave-uniform
+    unsigned yvoff;           // bytes from ynext to this lane's 8 hh-th channels of its (clamped) row
 #define ACX_Y_ROWS(t_)                                                                                          \
         {                                                                                                       \
+            long long t0_ = (long long)(t_) * Cfg::kPix;                                                        \
+            if (t0_ >= M) t0_ = M - 1;                                                                          \
             long long r_ = (long long)(t_) * Cfg::kPix + wave * 32 + l31;                                       \
             if (r_ >= M) r_ = M - 1;                                                                            \
-            ynext = y + r_ * C + 8 * hh;                                                                        \
+            ynext = y + t0_ * C;                                                                                \
+            yvoff = (unsigned)(((r_ - t0_) * C + 8 * hh) * 4);                                                  \
         }
-#define ACX_YREQ(q_) acx_glds16_own_m0(ynext + (16 * ((q_) >> 1) + 4 * ((q_) & 1)), __builtin_amdgcn_readfirstlane(my_y_a + (q_) * 1024));
+#define ACX_YREQ(q_) acx_glds16_s(ynext + (16 * ((q_) >> 1) + 4 * ((q_) & 1)), yvoff, __builtin_amdgcn_readfirstlane(my_y_a + (q_) * 1024));
 
     long long tile = blockIdx.x;              // the launcher keeps gridDim.x <= ntiles
     // ---- kernel prologue: the first tile's weights (W1c 0..2 / W2c 0) and y rows ---------------------------------------

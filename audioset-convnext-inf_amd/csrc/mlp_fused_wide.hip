@@ -162,13 +162,16 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     // defeats the two-unit look-ahead of the fragment reads; the counted waits at the segment ends are this file's own)
     const unsigned smem_a = acx_lds_addr(smem);
     // pieces 8 g .. 8 g + 7 of a segment share one M0 / base pair, set at the group's first piece and centred on its fifth
+    // (round 5: the base is a SCALAR -- the wave's first piece of the run -- and the lane contributes 16 x lane as a 32-bit offset:
+    // split_math.h acx_glds16_run_s; the 64-bit address per lane of the earlier form made a piece's issue several times dearer)
     const char* wbase = wstream;
+    const unsigned dma_voff = lane * 16;
 #define ACX_WDMA(seg_, piece_, grp_)                                                                             \
         {   if ((piece_) % 8 == 0) {                                                                             \
-                wbase = wstream + (long long)(seg_) * Cfg::kSegBytes + dma_lane + ((piece_) + 4) * 1024;         \
+                wbase = wstream + (long long)(seg_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_) + 4) * 1024;      \
                 acx_set_m0(__builtin_amdgcn_readfirstlane(smem_a + (grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_) + 4) * 1024)); \
             }                                                                                                    \
-            acx_glds16_run(wbase, (piece_) % 8); }
+            acx_glds16_run_s(wbase, dma_voff, (piece_) % 8); }
     // segments 0 and 1 are requested before anything else; segment s + 2 follows during segment s
 #pragma unroll
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(0, p, 0)

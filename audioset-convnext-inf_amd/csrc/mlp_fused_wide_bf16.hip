@@ -104,11 +104,14 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     }
 
     constexpr int n = Cfg::kChunks;
-    const int dma_lane = (wave * Cfg::kPieces) * 1024 + lane * 16;
+    // LDS-DMA pieces with a SCALAR base and a 32-bit lane offset (split_math.h acx_glds16_s, round 5): a piece's source is
+    // contiguous, so the 64-bit address per lane of the builtin form is not needed -- and that form's issue was 15 % of the paired
+    // kernel (profiles/r05_e_lds_dma_saddr.txt).  Issued from inline asm: the counted waits at the segment ends are this file's own.
+    const unsigned smem_a = acx_lds_addr(smem);
+    const unsigned dma_voff = lane * 16;
 #define ACX_WDMA(seg_, piece_, grp_)                                                                             \
-        __builtin_amdgcn_global_load_lds(                                                                        \
-            (const __attribute__((address_space(1))) void*)(wstream + (long long)(seg_) * Cfg::kSegBytes + dma_lane + (piece_) * 1024), \
-            (__attribute__((address_space(3))) void*)(smem + (grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_)) * 1024), 16, 0, 0);
+        acx_glds16_s(wstream + (long long)(seg_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_)) * 1024, dma_voff,   \
+                     smem_a + (unsigned)((grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_)) * 1024));
 #pragma unroll
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(0, p, 0)
 #pragma unroll
@@ -283,7 +286,8 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
         ACX_SEG_END(dma)
     };
 
-    __syncthreads();      // segments 0 and 1 landed (hipcc drains the LDS-DMA before the barrier); b1s visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // segments 0 and 1 landed (the pieces are issued from asm: hipcc does not wait for them)
+    __syncthreads();      // ... in every wave; b1s visible
     phase1(std::false_type{}, 0, 0, 0);
     ACX_MICRO_RANGE(0, 0, Cfg::kHalf)
     int grp = 1;
@@ -499,8 +503,7 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
 #pragma unroll
     for (int p = 0; p < kStreamBytes / 1024 / 8; ++p) {
         const int piece = wave * (kStreamBytes / 1024 / 8) + p;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wstream + piece * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, 0, 0);
+        acx_glds16_s(wstream + piece * 1024, lane * 16, acx_lds_addr(smem) + (unsigned)(piece * 1024));
     }
     for (int i = tid; i < 4 * C; i += 512) b1s[i] = b1[i];
     if (tid < C) b2s[tid] = b2[tid];

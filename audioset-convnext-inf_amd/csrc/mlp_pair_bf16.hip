@@ -123,9 +123,13 @@ __global__ __launch_bounds__(512) void mlp_pair_bf16_kernel(
         const int piece = q - second * P;
         const int pos = second ? pos1 : pos0;
         const char* src = wstream + (long long)pos * SEG + piece * 1024 + lane * 16;
-#ifndef ACX_PAIR_NODMA       // (lab ablation: wrong results, timing only)
+#ifdef ACX_PAIR_VADDR        // (lab: the 64-bit per-lane address form, acx_glds16_own_m0 -- 15 % of the kernel: profiles/r05_e_lds_dma_saddr.txt)
         acx_glds16_own_m0(src, smem_a + (unsigned)((pos & 3) * SEG + piece * 1024));
-#else
+#elif !defined(ACX_PAIR_NODMA)
+        // scalar base + 32-bit lane offset (global_load_lds_dwordx4 v, s[..]): the piece's address is wave-uniform apart from 16 x lane
+        (void)src;
+        acx_glds16_s(wstream + (long long)pos * SEG + piece * 1024, lane * 16, smem_a + (unsigned)((pos & 3) * SEG + piece * 1024));
+#else       // (NODMA: lab ablation, wrong results, timing only)
         asm volatile("" :: "v"(src));
 #endif
     };

@@ -27,6 +27,13 @@ __device__ __forceinline__ void acx_glds16(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void acx_glds16_own_m0(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// The same with a SCALAR base and a 32-bit lane offset (global_load_lds_dwordx4 voff, s[base:base+1]): for a piece whose source is
+// contiguous -- lane l fetches base + voff(l) -- the 64-bit address per lane of the form above is not needed, and the issue of the
+// piece is several times cheaper: the paired bf16 MLP spends 15 % of its time on the per-lane-address form and none measurable on
+// this one (round 5, profiles/r05_e_lds_dma_saddr.txt).  Same M0 contract as acx_glds16_own_m0; gbase must be wave-uniform.
+__device__ __forceinline__ void acx_glds16_s(const void* gbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
 // A RUN of pieces that are 1 KB apart in the stream AND in the LDS (a wave's pieces of one segment): the immediate offset of
 // global_load_lds applies to both addresses (verified on the part: offset:1024 moves source and destination by 1 KB), so one
 // M0 write + one 64-bit base serve up to eight pieces (13-bit signed immediate: -4096 .. 3072) and a piece is ONE instruction
@@ -39,6 +46,16 @@ __device__ __forceinline__ void acx_set_m0(unsigned lds_dst) {
 // immediate is part of the instruction.
 __device__ __forceinline__ void acx_glds16_run(const void* gbase, int j) {
 #define ACX_GLDS_CASE(J_) case J_: asm volatile("global_load_lds_dwordx4 %0, off offset:%1" :: "v"(gbase), "n"(((J_) - 4) * 1024) : "memory"); break;
+    switch (j) {
+        ACX_GLDS_CASE(0) ACX_GLDS_CASE(1) ACX_GLDS_CASE(2) ACX_GLDS_CASE(3)
+        ACX_GLDS_CASE(4) ACX_GLDS_CASE(5) ACX_GLDS_CASE(6) ACX_GLDS_CASE(7)
+        default: __builtin_unreachable();
+    }
+#undef ACX_GLDS_CASE
+}
+// The run form with a scalar base (see acx_glds16_s): piece j (0..7) of the run whose scalar base points at piece 4
+__device__ __forceinline__ void acx_glds16_run_s(const void* sbase, unsigned voff, int j) {
+#define ACX_GLDS_CASE(J_) case J_: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" :: "v"(voff), "s"(sbase), "n"(((J_) - 4) * 1024) : "memory"); break;
     switch (j) {
         ACX_GLDS_CASE(0) ACX_GLDS_CASE(1) ACX_GLDS_CASE(2) ACX_GLDS_CASE(3)
         ACX_GLDS_CASE(4) ACX_GLDS_CASE(5) ACX_GLDS_CASE(6) ACX_GLDS_CASE(7)
