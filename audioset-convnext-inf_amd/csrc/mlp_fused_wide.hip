@@ -157,7 +157,6 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_kernel(
     ACX_TILE_ROWS(tile)
 
     constexpr int n = Cfg::kChunks;
-    const int dma_lane = (wave * Cfg::kPieces) * 1024 + lane * 16;      // this lane's slot in piece 0 of its wave
     // (issued from inline asm: next to the builtin form hipcc waits lgkmcnt(0) / vmcnt(0) wherever an LDS read follows, which
     // defeats the two-unit look-ahead of the fragment reads; the counted waits at the segment ends are this file's own)
     const unsigned smem_a = acx_lds_addr(smem);
