@@ -38,7 +38,8 @@ typedef float dwm_f4 __attribute__((ext_vector_type(4)));
 typedef float dwm_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned dwm_u2 __attribute__((ext_vector_type(2)));
 
-// lab builds only (tools/lab/dwm_lab.hip): 1 no MFMAs, 2 no DMA, 3 no stores, 4 no LDS reads / packing (timing, wrong results)
+// lab builds only (tools/lab/dwm_lab.hip): 2 no DMA (the ring keeps stale bytes), 5 every store goes to the sink, 6 no MFMAs of the
+// tile above (kernel rows 4-6) (timing, wrong results)
 #ifndef ACX_DWM_ABLATE
 #define ACX_DWM_ABLATE 0
 #endif
@@ -51,8 +52,8 @@ __device__ unsigned long long acx_dwm_stamps[4096 * 16];
 #define ACX_DWM_STAMP(k_)
 #endif
 
-constexpr int kDwmRing = 16;             // ring rows (stacked row v sits in slot v & 15)
-constexpr int kDwmD = 3;                 // steps a row is requested ahead of the step that first reads it
+constexpr int kDwmD = 2;                 // steps (of four rows) a row is requested ahead of the step that first reads it
+constexpr int kDwmRing = 4 * kDwmD + 4;  // ring rows: a step reads rows s - 3 .. s + 4 while rows up to s + 4 D + 4 are requested
 constexpr int kDwmTabB = 7 * 16 * 64;    // weight table: [kernel row][tap + 4, 16 entries][32 channels] bf16
 
 // S output quads; LEFT / RIGHT: the strip has an input quad left / right of its output quads (inside the image)
@@ -75,7 +76,8 @@ template <int W> struct DwmGeom {
     static constexpr int kStrips = (kNQ + kSMax - 1) / kSMax;       // 5 (3 3 3 3 2), 2 (4 3), 1 (4)
     static constexpr int kUnits = kStrips * (kC / 32);
     static constexpr int kQMax = W == 14 ? 4 : 5;                   // input quads of the widest strip
-    static constexpr int kWaveLds = (kDwmRing + 1) * (kQMax * 256 + 32) + kDwmTabB;
+    static constexpr int kWaveLds = (kDwmRing + 1) * (kQMax * 256 + 32);      // + 1: the dummy row; the weight table (7 KB) lives in the ring's bytes before the first request
+    static_assert(kWaveLds >= kDwmTabB, "the weight table must fit the ring");
     static constexpr size_t kLdsBytes = (size_t)4 * kWaveLds;
 };
 
@@ -94,78 +96,14 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
                                         const float* __restrict__ bias, char* sink, char* lds, int B, int H, int steps2, int seg,
                                         int slice, int jt0, unsigned magic, int item) {
     using Cfg = DwmCfg<W, S, LEFT, RIGHT>;
-    constexpr int C = Cfg::kC, Q = Cfg::kQ, kPitch = Cfg::kPitch;
+    constexpr int C = Cfg::kC, Q = Cfg::kQ, kPitch = Cfg::kPitch, R = kDwmRing;
     const int lane = threadIdx.x & 63, cl = lane >> 2, q = lane & 3;
     char* const ring = lds;
-    char* const tab = lds + DwmGeom<W>::kWaveLds - kDwmTabB;
+    char* const tab = lds;                                 // the weight table lives where the ring will: it is dead before the first request
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
     const int ch0 = slice * 32;
     const int col_in0 = 4 * (jt0 - LEFT);
     ACX_DWM_STAMP(0)
-
-    // ---- the request side: lane -> (pixel of the piece, 16-byte chunk of its 64-byte channel slice)
-    unsigned voff[Cfg::kPieces];
-    bool vok[Cfg::kPieces];
-#pragma unroll
-    for (int p = 0; p < Cfg::kPieces; ++p) {
-        const int px = p * 16 + (lane >> 2);
-        vok[p] = px < Cfg::kCols;
-        voff[p] = (unsigned)(((col_in0 + (vok[p] ? px : 0)) * C + ch0) * 2 + (lane & 3) * 16);
-    }
-    const int vb = seg * 8 * steps2;                       // first output row (stacked) of the segment
-    // Two cursors walk the stacked image row by row, in scalar registers (a division per row and request cost 360 cycles of
-    // branches per request): clip n, row r of the clip (r >= H: one of the three rows between clips), pointer to the next image row.
-    const int Hp = H + 3;
-    int qn, qr, qslot;                                     // the request cursor
-    const char* qptr;
-    {
-        const int v0 = vb - 3 + Hp;                        // >= 0
-        const int n1 = (int)__umulhi((unsigned)v0, magic);
-        qr = v0 - n1 * Hp; qn = n1 - 1;
-        qptr = x + ((long long)qn * H + (qr < H ? qr : H)) * Cfg::kGRowB;
-        qslot = (vb - 3) & (kDwmRing - 1);
-    }
-    const char* safe_src = x + (long long)(qn < 0 ? 0 : (qn < B ? qn : B - 1)) * H * Cfg::kGRowB;   // for the requests of non-image rows: a row of this wave's own neighbourhood
-    auto request = [&]() {
-        const bool real = qr < H && (unsigned)qn < (unsigned)B;
-        const unsigned slot = (unsigned)qslot * kPitch;
-        const char* const src = real ? qptr : safe_src;
-        const unsigned dst = ring_lds + (real ? slot : (unsigned)(kDwmRing * kPitch));
-        if (!real) {                                       // rare: zeros by the wave itself, the request lands in the dummy row
-#pragma unroll
-            for (int p = 0; p < Cfg::kPieces; ++p)
-                if (vok[p]) *reinterpret_cast<dwm_f4*>(ring + slot + p * 1024 + lane * 16) = dwm_f4{0.f, 0.f, 0.f, 0.f};
-        }
-        safe_src = src;
-        qptr += real ? Cfg::kGRowB : 0;
-        qslot = (qslot + 1) & (kDwmRing - 1);
-        const bool wrap = qr + 1 == Hp;
-        qr = wrap ? 0 : qr + 1;
-        qn += wrap ? 1 : 0;
-        if (ACX_DWM_ABLATE == 2) return;
-#pragma unroll
-        for (int p = 0; p < Cfg::kPieces; ++p)
-            if (vok[p]) acx_glds16_s(dwm_scalar(src), voff[p], __builtin_amdgcn_readfirstlane(dst + p * 1024));
-    };
-    int on, orow;                                          // the output cursor
-    char* optr;
-    {
-        const int n = (int)__umulhi((unsigned)vb, magic);
-        on = n; orow = vb - n * Hp;
-        optr = y + ((long long)n * H + (orow < H ? orow : H)) * Cfg::kGRowB;
-    }
-
-    // W = 14: columns 14 and 15 of every ring row are zeros no request ever writes
-    if constexpr (Cfg::kCols < 4 * Q) {
-        for (int i = lane; i < (kDwmRing + 1) * (4 * Q - Cfg::kCols) * 4; i += 64) {
-            const int c = i & 3, px = Cfg::kCols + (i >> 2) % (4 * Q - Cfg::kCols), row = (i >> 2) / (4 * Q - Cfg::kCols);
-            *reinterpret_cast<dwm_f4*>(ring + row * kPitch + px * 64 + c * 16) = dwm_f4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    // rows of step 0 (the window vb - 3 .. vb + 6 and the four new rows of the step): requested before anything else
-#pragma unroll 1
-    for (int v = vb - 3; v <= vb + 10; ++v) request();
-    ACX_DWM_STAMP(1)
 
     // ---- weights: bf16 table [kh][te = tap + 4][channel], then the lane's operands B[kh][d = kq - jt + 1][set]
     {
@@ -202,108 +140,195 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
                 Bw[kh][d][1] = dwm_op(dwm_hi(L[0], L[1]), dwm_hi(L[2], L[3]));
             }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the table has been read: its bytes are ring rows from here on
+    ACX_DWM_STAMP(1)
 
+    // ---- the request side: lane -> (pixel of the piece, 16-byte chunk of its 64-byte channel slice)
+    unsigned voff[Cfg::kPieces];
+    bool vok[Cfg::kPieces];
+#pragma unroll
+    for (int p = 0; p < Cfg::kPieces; ++p) {
+        const int px = p * 16 + (lane >> 2);
+        vok[p] = px < Cfg::kCols;
+        voff[p] = (unsigned)(((col_in0 + (vok[p] ? px : 0)) * C + ch0) * 2 + (lane & 3) * 16);
+    }
+    const int Lrows = 8 * steps2;
+    const int vb = seg * Lrows;                            // first output row (stacked) of the segment
+    // Two cursors walk the stacked image row by row, in scalar registers (a division per row and request cost 360 cycles of
+    // branches per request): clip n, row r of the clip (r >= H: one of the three rows between clips), pointer to the next image row.
+    const int Hp = H + 3;
+    int qn, qr, qleft = Lrows + 6;                         // the request cursor; rows the segment still needs: vb - 3 .. vb + L + 2
+    unsigned qoff = 0;                                     // byte offset of its ring slot (row vb - 3 sits in slot 0)
+    const char* qptr;
+    {
+        const int v0 = vb - 3 + Hp;                        // >= 0
+        const int n1 = (int)__umulhi((unsigned)v0, magic);
+        qr = v0 - n1 * Hp; qn = n1 - 1;
+        qptr = x + ((long long)qn * H + (qr < H ? qr : H)) * Cfg::kGRowB;
+    }
+    const char* safe_src = x + (long long)(qn < 0 ? 0 : (qn < B ? qn : B - 1)) * H * Cfg::kGRowB;   // for the requests of non-image rows: a row of this wave's own neighbourhood
+    // One request per call, always (the counted waits rely on it).  A row between clips: zeros written by the wave itself, the
+    // request re-reads the wave's latest row into the dummy row; a row past the segment's last: the same without the zeros.
+    auto request = [&]() {
+        const bool need = qleft > 0;
+        const bool real = need && qr < H && (unsigned)qn < (unsigned)B;
+        const char* const src = real ? qptr : safe_src;
+        const unsigned dst = ring_lds + (real ? qoff : (unsigned)(R * kPitch));
+        if (need && !real) {
+#pragma unroll
+            for (int p = 0; p < Cfg::kPieces; ++p)
+                if (vok[p]) *reinterpret_cast<dwm_f4*>(ring + qoff + p * 1024 + lane * 16) = dwm_f4{0.f, 0.f, 0.f, 0.f};
+        }
+        safe_src = src;
+        qptr += real ? Cfg::kGRowB : 0;
+        qoff = qoff + kPitch == (unsigned)(R * kPitch) ? 0u : qoff + kPitch;
+        const bool wrap = qr + 1 == Hp;
+        qr = wrap ? 0 : qr + 1;
+        qn += wrap ? 1 : 0;
+        qleft -= 1;
+        if (ACX_DWM_ABLATE == 2) return;
+#pragma unroll
+        for (int p = 0; p < Cfg::kPieces; ++p)
+            if (vok[p]) acx_glds16_s(dwm_scalar(src), voff[p], __builtin_amdgcn_readfirstlane(dst + p * 1024));
+    };
+    int on, orow;                                          // the output cursor
+    char* optr;
+    {
+        const int n = (int)__umulhi((unsigned)vb, magic);
+        on = n; orow = vb - n * Hp;
+        optr = y + ((long long)n * H + (orow < H ? orow : H)) * Cfg::kGRowB;
+    }
+
+    // W = 14: columns 14 and 15 of every ring row are zeros no request ever writes
+    if constexpr (Cfg::kCols < 4 * Q) {
+        for (int i = lane; i < R * (4 * Q - Cfg::kCols) * 4; i += 64) {
+            const int c = i & 3, px = Cfg::kCols + (i >> 2) % (4 * Q - Cfg::kCols), row = (i >> 2) / (4 * Q - Cfg::kCols);
+            *reinterpret_cast<dwm_f4*>(ring + row * kPitch + px * 64 + c * 16) = dwm_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // the first R rows: vb - 3 .. vb + 4 D (everything the steps before the first in-loop request's target read)
+#pragma unroll 1
+    for (int i = 0; i < R; ++i) request();
     ACX_DWM_STAMP(2)
-    // ---- the data side: a group = relative row rho (lane q reads stacked row rho + q), all Q quads, both channel sets
-    dwm_s4 A[8][Q][2];
+
+    // ---- the data side: group g (lane q reads stacked row g - 3 + q), all Q quads, both channel sets.  A group meets kernel row
+    // kh1 = g mod 4 of the tile its rows start (X) and kernel row kh1 + 4 of the tile above (Y): nothing but the current group's
+    // operands and the two tiles' accumulators is kept in registers.
     unsigned raw[Q][4];
-    auto fetch = [&](int rho) {
-        if (ACX_DWM_ABLATE == 4) return;
-        const char* p = ring + (unsigned)((rho + q) & (kDwmRing - 1)) * kPitch + cl * 4;
+    int fidx = 0;                                          // ring slot of the next group's first row
+    auto fetch = [&]() {
+        unsigned t = (unsigned)fidx + (unsigned)q;
+        t = min(t, t - (unsigned)R);                       // t >= R: wrap (unsigned: t - R is huge otherwise)
+        const char* p = ring + t * kPitch + cl * 4;
 #pragma unroll
         for (int kq = 0; kq < Q; ++kq)
 #pragma unroll
             for (int e = 0; e < 4; ++e) raw[kq][e] = *reinterpret_cast<const unsigned*>(p + (kq * 4 + e) * 64);
+        fidx = fidx + 1 == R ? 0 : fidx + 1;
     };
-#define ACX_DWM_PACK(slot_)                                                                                     \
-    if (ACX_DWM_ABLATE != 4) {                                                                                  \
-        _Pragma("unroll") for (int kq_ = 0; kq_ < Q; ++kq_) {                                                   \
-            A[slot_][kq_][0] = dwm_op(dwm_lo(raw[kq_][0], raw[kq_][1]), dwm_lo(raw[kq_][2], raw[kq_][3]));      \
-            A[slot_][kq_][1] = dwm_op(dwm_hi(raw[kq_][0], raw[kq_][1]), dwm_hi(raw[kq_][2], raw[kq_][3]));      \
-        }                                                                                                       \
-    }
-    if (ACX_DWM_ABLATE == 4) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int kq = 0; kq < Q; ++kq) { A[s][kq][0] = dwm_op(lane + s, kq); A[s][kq][1] = dwm_op(lane, kq + s); }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ACX_DWM_STAMP(3)
-    fetch(vb - 3); ACX_DWM_PACK(0) fetch(vb - 2); ACX_DWM_PACK(1) fetch(vb - 1); ACX_DWM_PACK(2) fetch(vb); ACX_DWM_PACK(3)
-    fetch(vb + 1); ACX_DWM_PACK(4) fetch(vb + 2); ACX_DWM_PACK(5) fetch(vb + 3); ACX_DWM_PACK(6)
-    // rows of the steps 1 .. kDwmD - 1
-#pragma unroll 1
-    for (int v = vb + 11; v <= vb + 4 * (kDwmD - 1) + 10; ++v) request();
-
-    ACX_DWM_STAMP(4)
     const unsigned lane_off = (unsigned)(((4 * jt0 + q) * C + ch0 + 2 * cl) * 2);
     char* const slane = sink + lane_off;
     const dwm_f4 b0 = {bv.x, bv.x, bv.x, bv.x}, b1 = {bv.y, bv.y, bv.y, bv.y};
+    dwm_f4 acc[2][S][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int jt = 0; jt < S; ++jt) { acc[t][jt][0] = b0; acc[t][jt][1] = b1; }
 
-    // One step: output rows r0 .. r0 + 3; P0 = the register slot of kernel row 0 (0 / 4 alternating).  New group m (relative row
-    // r0 + 4 + m) goes to slot P0 + 7 + m: the spare slot, then the slots of kernel rows 0, 1, 2 as they retire.
-#define ACX_DWM_KH(P0_, kh_)                                                                                    \
-    if (ACX_DWM_ABLATE != 1) {                                                                                  \
-        _Pragma("unroll") for (int jt_ = 0; jt_ < S; ++jt_)                                                     \
-            _Pragma("unroll") for (int d_ = 0; d_ < 3; ++d_) {                                                  \
-                const int kq_ = jt_ + d_ - 1 + LEFT;                                                            \
-                if (kq_ < 0 || kq_ >= Q) continue;                                                              \
-                acc[jt_][0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(A[((P0_) + (kh_)) & 7][kq_][0], Bw[kh_][d_][0], acc[jt_][0], 0, 0, 0); \
-                acc[jt_][1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(A[((P0_) + (kh_)) & 7][kq_][1], Bw[kh_][d_][1], acc[jt_][1], 0, 0, 0); \
-            }                                                                                                   \
-    }
-#define ACX_DWM_STEP(P0_)                                                                                       \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ACX_DWM_STAMP(3)
+    fetch();
+    ACX_DWM_STAMP(4)
+
+#define ACX_DWM_KH(t_, kh_)                                                                                     \
+    _Pragma("unroll") for (int jt_ = 0; jt_ < S; ++jt_)                                                         \
+        _Pragma("unroll") for (int d_ = 0; d_ < 3; ++d_) {                                                      \
+            const int kq_ = jt_ + d_ - 1 + LEFT;                                                                \
+            if (kq_ < 0 || kq_ >= Q) continue;                                                                  \
+            acc[t_][jt_][0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Ac[kq_][0], Bw[kh_][d_][0], acc[t_][jt_][0], 0, 0, 0); \
+            acc[t_][jt_][1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Ac[kq_][1], Bw[kh_][d_][1], acc[t_][jt_][1], 0, 0, 0); \
+        }
+    // group P of the eight-group period (P >> 2: which accumulator set is X); TAIL: the groups below the segment's last tile
+#define ACX_DWM_GROUP(P_, TAIL_)                                                                                \
     {                                                                                                           \
-        /* the first pair of steps reads rows the prologue requested: fewer requests behind them than kWait counts */ \
-        if (n2 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+        dwm_s4 Ac[Q][2];                                                                                        \
+        _Pragma("unroll") for (int kq_ = 0; kq_ < Q; ++kq_) {                                                   \
+            Ac[kq_][0] = dwm_op(dwm_lo(raw[kq_][0], raw[kq_][1]), dwm_lo(raw[kq_][2], raw[kq_][3]));            \
+            Ac[kq_][1] = dwm_op(dwm_hi(raw[kq_][0], raw[kq_][1]), dwm_hi(raw[kq_][2], raw[kq_][3]));            \
+        }                                                                                                       \
+        fetch();                                                                                                \
+        if (!(TAIL_)) { ACX_DWM_KH(((P_) >> 2) & 1, (P_) & 3) }                                                 \
+        if (((P_) & 3) < 3 && ACX_DWM_ABLATE != 6) { ACX_DWM_KH((((P_) >> 2) & 1) ^ 1, ((P_) & 3) + 4) }        \
+    }
+    // a step = four groups; the tile above (Y) is complete after the third and leaves; its registers start the tile below
+#define ACX_DWM_STEP(H_, TAIL_)                                                                                 \
+    {                                                                                                           \
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ACX_DWM_ABLATE == 2 ? 0 : Cfg::kWait) : "memory");           \
-        dwm_f4 acc[S][2];                                                                                       \
-        _Pragma("unroll") for (int jt_ = 0; jt_ < S; ++jt_) { acc[jt_][0] = b0; acc[jt_][1] = b1; }             \
-        fetch(r0 + 4);                                                                                          \
-        ACX_DWM_KH(P0_, 0) ACX_DWM_PACK(((P0_) + 7) & 7) fetch(r0 + 5);                                         \
-        ACX_DWM_KH(P0_, 1) ACX_DWM_PACK(((P0_) + 0) & 7) fetch(r0 + 6);                                         \
-        ACX_DWM_KH(P0_, 2) ACX_DWM_PACK(((P0_) + 1) & 7) fetch(r0 + 7);                                         \
-        ACX_DWM_KH(P0_, 3) ACX_DWM_PACK(((P0_) + 2) & 7)                                                        \
-        ACX_DWM_KH(P0_, 4) ACX_DWM_KH(P0_, 5) ACX_DWM_KH(P0_, 6)                                                \
+        ACX_DWM_STORE()                                                                                         \
+        ACX_DWM_GROUP(4 * (H_) + 0, TAIL_) ACX_DWM_GROUP(4 * (H_) + 1, TAIL_) ACX_DWM_GROUP(4 * (H_) + 2, TAIL_) \
+        if (!(TAIL_)) ACX_DWM_GROUP(4 * (H_) + 3, TAIL_)                                                        \
+        _Pragma("unroll") for (int jt_ = 0; jt_ < S; ++jt_) {                                                   \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) outp[jt_][i_] = acx_pack_bf16x2(acc[(H_) ^ 1][jt_][0][i_], acc[(H_) ^ 1][jt_][1][i_]); \
+            acc[(H_) ^ 1][jt_][0] = b0; acc[(H_) ^ 1][jt_][1] = b1;                                             \
+        }                                                                                                       \
+        if (!(TAIL_)) { request(); request(); request(); request(); }                                           \
+    }
+    // The tile a step completes leaves at the START of the next step, behind that step's wait: a store sits in the same in-order
+    // queue as the requests, and the wait of step s + 1 must not stand behind stores issued one step earlier (their
+    // acknowledgement takes as long as a row takes to arrive: WAIT_INST was half of every wave's life in stage 0).
+#define ACX_DWM_STORE()                                                                                         \
+    {                                                                                                           \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                      \
-            const bool real_ = orow < H && on < B;                                                              \
+            const bool real_ = ACX_DWM_ABLATE != 5 && live > 1 && orow < H && on < B;                           \
             char* const d_ = real_ ? optr + lane_off : slane;                                                   \
             optr += real_ ? Cfg::kGRowB : 0;                                                                    \
-            { const bool wrap_ = orow + 1 == Hp; orow = wrap_ ? 0 : orow + 1; on += wrap_ ? 1 : 0; }            \
-            _Pragma("unroll") for (int jt_ = 0; jt_ < (ACX_DWM_ABLATE == 3 ? 0 : S); ++jt_) {                   \
+            { const bool wrap_ = orow + 1 == Hp; orow = live > 1 ? (wrap_ ? 0 : orow + 1) : orow; on += (live > 1 && wrap_) ? 1 : 0; } \
+            _Pragma("unroll") for (int jt_ = 0; jt_ < S; ++jt_) {                                               \
                 char* p_ = d_ + jt_ * 4 * C * 2;                                                                \
-                if (W == 14 && jt_ == S - 1 && q >= 2) p_ = slane + jt_ * 4 * C * 2;                            \
-                *reinterpret_cast<unsigned*>(p_) = acx_pack_bf16x2(acc[jt_][0][i_], acc[jt_][1][i_]);           \
+                if (W == 14 && LEFT + jt_ == 3 && q >= 2) p_ = slane + jt_ * 4 * C * 2;                         \
+                *reinterpret_cast<unsigned*>(p_) = outp[jt_][i_];                                               \
             }                                                                                                   \
         }                                                                                                       \
-        request(); request(); request(); request();                                                             \
-        r0 += 4;                                                                                                \
+        live += 1;                                                                                              \
     }
-    int r0 = vb;
+    unsigned outp[S][4];                                   // the finished tile, packed: stored by the next step
+#pragma unroll
+    for (int jt = 0; jt < S; ++jt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) outp[jt][i] = 0u;
+    int live = 0;                                          // stores 0 and 1 carry nothing (no tile yet; the tile above the segment): sink
 #pragma unroll 1
     for (int n2 = 0; n2 < steps2; ++n2) {
-        ACX_DWM_STEP(0)
-        ACX_DWM_STEP(4)
+        ACX_DWM_STEP(0, false)
+        ACX_DWM_STEP(1, false)
         ACX_DWM_STAMP(5 + n2)
     }
+    ACX_DWM_STEP(0, true)
+    ACX_DWM_STORE()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ACX_DWM_STAMP(15)
 #undef ACX_DWM_STEP
+#undef ACX_DWM_STORE
+#undef ACX_DWM_GROUP
 #undef ACX_DWM_KH
-#undef ACX_DWM_PACK
 }
 
 template <int W>
-__global__ __launch_bounds__(256) void dwconv7_mfma_kernel(const void* __restrict__ x_, void* __restrict__ y_, const float* __restrict__ wt /*[49][C]*/,
+__global__ __launch_bounds__(256, 2) void dwconv7_mfma_kernel(const void* __restrict__ x_, void* __restrict__ y_, const float* __restrict__ wt /*[49][C]*/,
                                                            const float* __restrict__ bias, void* __restrict__ sink_, int B, int H,
                                                            int steps2 /* pairs of 4-row steps per segment */, int n_items, unsigned magic) {
     using G = DwmGeom<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int item = min((int)blockIdx.x * 4 + wave, n_items - 1);       // a wave past the last item repeats it (identical stores)
+    // Consecutive workgroups go to different XCDs (round-robin over 8): logical block = the blockIdx-th in XCD-major order, so
+    // that neighbours in the item order -- the other half of every 128-B line (the next slice), the strip next door (a shared
+    // quad column), the segment below (six shared rows) -- meet in ONE L2 instead of being fetched by two.
+    const int nb = (int)gridDim.x, per = nb >> 3, rem = nb & 7, xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+    const int lblock = xcd * per + (xcd < rem ? xcd : rem) + k;
+    const int item = min(lblock * 4 + wave, n_items - 1);              // a wave past the last item repeats it (identical stores)
+    // slice fastest: a pixel's 64-byte slices (halves of 128-byte lines) are read by neighbouring waves of one workgroup
     const int unit = item % G::kUnits, seg = item / G::kUnits;
-    const int strip = unit % G::kStrips, slice = unit / G::kStrips;
+    const int slice = unit % (G::kC / 32), strip = unit / (G::kC / 32);
     const char* x = reinterpret_cast<const char*>(x_);
     char* y = reinterpret_cast<char*>(y_);
     char* sink = reinterpret_cast<char*>(sink_) + (size_t)(item % kDwSinkWindows) * kDwSinkWindowBytes;

@@ -147,6 +147,10 @@ int main(int argc, char** argv) {
     }
     return 0;
 #endif
+#ifdef DWM_PMC
+    run_case(64, 63, 14, 2, waves, false); run_case(64, 126, 28, 2, waves, false); run_case(64, 252, 56, 2, waves, false);
+    return 0;
+#endif
 #ifdef DWM_ONLY
     run_case(64, 63, 14, 20, waves, false);
     run_case(64, 126, 28, 20, waves, false);
