@@ -37,6 +37,7 @@ SIGNATURES = {
     "acx_logmel_bn0": (_c_int, [_vp, _vp, _c_int, _c_i64, _vp, _c_int, _vp]),
     "acx_stem_ln": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp]),
     "acx_dwconv7": (_c_int, [_vp, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
+    "acx_dwconv7_bf16": (_c_int, [_vp, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "acx_block": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _c_sz, _vp]),
     "acx_block_scratch_bytes": (_c_int, [_c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_sz)]),
     "acx_downsample": (_c_int, [_vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),

@@ -114,6 +114,7 @@ struct HostTensor {
 struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layouts
     float* dw = nullptr;     // [49][C]   tap-major depthwise weights
     float* dwb = nullptr;    // [C]
+    uint16_t* dw_ops = nullptr; // bf16a, stages 0-2: the depthwise weights as the B operands of dwconv_mfma.hip: [C/32][7][3][2][64 lanes][4] bf16
     float* w1 = nullptr;     // [4C][C]   pwconv1 with the LayerNorm weight folded in
     float* b1 = nullptr;     // [4C]      pwconv1 bias + W1 . ln_bias
     float* w1sum = nullptr;  // [4C]      sum_k w1[n][k]  (LayerNorm applied in the GEMM epilogue)
@@ -228,6 +229,7 @@ struct Tuning {
     std::atomic<int> fail_sub{-1};     // acx_test_fail_sub(i): acx_forward reports a failure after queueing sub-batch i (error-path tests; never read from the environment)
     std::atomic<int> wide_pers{0};     // ACX_WIDE_PERSIST: 1 = persistent wide fused MLP wherever it exists, 2 = never; 0 = by launch size
     std::atomic<int> bf16_pair{-1};    // ACX_BF16_PAIR = 1: the paired (producer / consumer) fused bf16 MLP instead of the ring kernels (C = 192, 384); default: ring
+    std::atomic<int> dw_mfma{-1};      // ACX_DW_MFMA = 0: bf16 activations go through the column / tile depthwise kernels instead of the matrix-pipe kernel (A/B timing: other bits)
     std::atomic<int> dw_stream{-1};    // ACX_DW_STREAM = 0 | 1: forces the tile / column-streaming depthwise kernels (-1: by launch size)
 };
 Tuning& tuning();
@@ -273,6 +275,9 @@ constexpr size_t kDwSinkWindowBytes = 64 * 1024;      // >= a row's lane offsets
 constexpr size_t kDwSinkBytes = kDwSinkWindows * kDwSinkWindowBytes;
 int launch_dwconv_col(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H, int W,
                       bool act_bf16, int target_waves, hipStream_t s);
+// matrix-pipe form for bf16 activations (dwconv_mfma.hip): weights rounded to bf16, fp32 accumulation; every launch size
+int launch_dwconv_mfma(const void* x, void* y, const void* dw_ops, const float* bias, void* sink, int B, int H, int W,
+                       int target_waves, hipStream_t s);
 // element-wise fp32 <-> bf16 (the per-layer entry points of the C ABI keep fp32 tensors in every mode)
 int launch_convert_f32_to_bf16(const float* in, void* out, long long n, hipStream_t s);
 int launch_convert_bf16_to_f32(const void* in, float* out, long long n, hipStream_t s);

@@ -28,6 +28,7 @@ void tuning_reload() {
     t.wide_pers.store(digit("ACX_WIDE_PERSIST", "01", -1) < 0 ? 0 : (digit("ACX_WIDE_PERSIST", "01", 0) == 1 ? 1 : 2), std::memory_order_relaxed);
     t.gemm_32x32.store(digit("ACX_GEMM_32X32", "1", 0), std::memory_order_relaxed);
     t.dw_stream.store(digit("ACX_DW_STREAM", "01", -1), std::memory_order_relaxed);
+    t.dw_mfma.store(digit("ACX_DW_MFMA", "01", -1), std::memory_order_relaxed);
     t.bf16_pair.store(digit("ACX_BF16_PAIR", "01", -1), std::memory_order_relaxed);
 }
 
@@ -337,6 +338,25 @@ static int finalize_impl(acx_ctx* c) {
                 for (int tap = 0; tap < 49; ++tap) t[(size_t)tap * C + ch] = dw[(size_t)ch * 49 + tap];
             ACX_TRY(upload(c, t, &bw.dw));
             ACX_TRY(upload(c, dwb, &bw.dwb));
+            if (c->precision == ACX_PREC_BF16_ACT && s < 3) {
+                // dwconv_mfma.hip: the B operands of the 16-block 4x4x4 MFMA, one 8-byte load per lane and operand.  Operand
+                // (kernel row kh, d = input quad - output quad + 1, channel set) of lane (q = lane & 3, cl = lane >> 2) holds, for
+                // k = 0..3, the weight of tap 4 d + k - q - 1 of row kh (zero outside 0..6) of channel 32 slice + 2 cl + set.
+                std::vector<uint16_t> ops((size_t)(C / 32) * 42 * 64 * 4);
+                for (int sl = 0; sl < C / 32; ++sl)
+                    for (int kh = 0; kh < 7; ++kh)
+                        for (int d = 0; d < 3; ++d)
+                            for (int st = 0; st < 2; ++st)
+                                for (int lane = 0; lane < 64; ++lane) {
+                                    const int q = lane & 3, ch = 32 * sl + 2 * (lane >> 2) + st;
+                                    for (int k = 0; k < 4; ++k) {
+                                        const int tp = 4 * d + k - q - 1;
+                                        ops[((((size_t)(sl * 7 + kh) * 3 + d) * 2 + st) * 64 + lane) * 4 + k] =
+                                            (tp >= 0 && tp < 7) ? to_bf16(dw[(size_t)ch * 49 + kh * 7 + tp]) : (uint16_t)0;
+                                    }
+                                }
+                ACX_TRY(upload(c, ops, &bw.dw_ops));
+            }
             std::vector<float> f1((size_t)4 * C * C), fb1((size_t)4 * C), fs1((size_t)4 * C);
             for (int n = 0; n < 4 * C; ++n) {
                 double acc = b1[n], csum = 0.0;
@@ -1005,6 +1025,15 @@ int acx_dwconv7(acx_ctx* c, int stage, int block, const float* x, float* y, floa
     if (!x || !y || B <= 0 || H <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_dwconv7: bad argument");
     if (Wd != (kStemW >> stage)) ACX_FAIL(ACX_ERR_SHAPE, "stage %d has width %d, got %d", stage, kStemW >> stage, Wd);
     return launch_dwconv(c, c->blocks[stage][block], kDims[stage], x, y, stats, B, H, Wd, (hipStream_t)stream);
+}
+
+int acx_dwconv7_bf16(acx_ctx* c, int stage, int block, const uint16_t* x, uint16_t* y, int B, int H, int Wd, void* stream) {
+    ACX_TRY(need_ready(c));
+    ACX_TRY(check_stage(stage, block));
+    if (!x || !y || B <= 0 || H <= 0) ACX_FAIL(ACX_ERR_ARG, "acx_dwconv7_bf16: bad argument");
+    if (!act_bf16(c, stage)) ACX_FAIL(ACX_ERR_STATE, "acx_dwconv7_bf16: stage %d does not store bf16 activations at this precision", stage);
+    if (Wd != (kStemW >> stage)) ACX_FAIL(ACX_ERR_SHAPE, "stage %d has width %d, got %d", stage, kStemW >> stage, Wd);
+    return launch_dwconv(c, c->blocks[stage][block], kDims[stage], x, y, nullptr, B, H, Wd, (hipStream_t)stream, true);
 }
 
 int acx_block_scratch_bytes(int stage, int B, int H, int Wd, size_t* out_bytes) {

@@ -19,15 +19,24 @@
 //   * a lane = (q = lane & 3: row i of A, column j of B and D;  cl = lane >> 2: the channel block).  A lane reads 4 B = channels
 //     (2 cl, 2 cl + 1) of a pixel from the LDS; v_perm_b32 packs the low halves of two neighbouring pixels into an operand
 //     register of channel 2 cl and the high halves into one of channel 2 cl + 1: a wave works on 32 channels as two channel sets;
-//   * a WAVE owns a strip of S <= 4 output quads x 32 channels and walks DOWN a segment of the batch stacked as one tall image
-//     (dwconv.hip: H rows of a clip, 3 rows of zeros, the next clip), four output rows per step.  Lane q holds the seven input
-//     rows r0 + q - 3 .. r0 + q + 3 of the strip's Q <= 5 input quads as packed operands (8 row slots x Q quads x 2 sets x 2
-//     registers); a step retires four of them and loads four (each LDS row is read by four lanes: x4 LDS reads, all the
-//     re-use of a row across the 7 kernel rows and 3 output quads happens in registers);
-//   * rows arrive by LDS-DMA into a ring of 16 rows PRIVATE to the wave (no barrier in the kernel, counted s_waitcnt vmcnt as in
-//     dwconv_col.hip); a row's pitch is Q x 256 + 32 B, so the four rows a 32-lane group of a read touches fall into different banks;
-//     rows between clips are ring rows the wave zeroes itself (their request goes to a dummy row, the count stays fixed);
-//   * the 21 x 2 weight operands of a lane are built once per wave through a bf16 table in the LDS.
+//   * the INPUT streams: group g = the rows g - 3 + q of the four lanes q (every LDS row is read by four consecutive groups), all
+//     Q <= 6 input quads of the wave's strip.  A group meets kernel row g mod 4 of the output tile its rows start (X) and kernel row
+//     g mod 4 + 4 of the tile above (Y), and is gone: registers hold the operands of ONE group, the raw pixels of the next, the
+//     accumulators of two tiles of S <= 4 output quads (64) and the 21 x 2 weight operands (84) -- 220, two waves per SIMD, which
+//     is what lets the packing of one wave run under the MFMAs of the other (one wave per SIMD with a 7-row window of packed
+//     operands in registers, the first form, only matched the column kernel: profiles/r05_f_dwconv_mfma_v1_lab.txt);
+//   * a GROUP of waves (4 / 2 / 1 for W = 56 / 28 / 14) splits an image row into strips of 4 4 3 3 / 4 3 / 4 output quads and
+//     shares ONE ring of 16 whole rows of the slice: every wave requests a 1-KB piece of each row (LDS-DMA, counted s_waitcnt vmcnt),
+//     one s_barrier per step says that everybody's pieces have landed and that the rows of the step before are free.  No strip re-reads
+//     its neighbours' columns from the L2: private rings with halo quads moved 5/3 of the input and sat on the rate this access
+//     pattern gets from the L2 (profiles/r05_f_halfline_bench.txt).  A row's pitch is NQ x 256 + 32 B: the four rows a 32-lane group
+//     of a ds_read_b32 touches fall into different banks.  Rows between clips are ring rows the waves zero themselves (their
+//     request re-reads an old row into a dummy row: the count stays fixed);
+//   * a finished tile is packed to bf16 and leaves at the start of the NEXT step, behind that step's wait: stores sit in the same
+//     in-order queue as the requests, and a wait must not stand behind stores that were issued a step ago;
+//   * the weight operands are packed once per model in exactly the register form (api.hip, BlockW::dw_ops): 42 loads per wave;
+//   * workgroups are numbered XCD-major and slices vary fastest: the two 64-byte halves of a 128-byte line and the six rows two
+//     segments share meet in one L2.
 #include "acx_internal.h"
 #include "split_math.h"
 
@@ -53,32 +62,28 @@ __device__ unsigned long long acx_dwm_stamps[4096 * 16];
 #endif
 
 constexpr int kDwmD = 2;                 // steps (of four rows) a row is requested ahead of the step that first reads it
-constexpr int kDwmRing = 4 * kDwmD + 4;  // ring rows: a step reads rows s - 3 .. s + 4 while rows up to s + 4 D + 4 are requested
-constexpr int kDwmTabB = 7 * 16 * 64;    // weight table: [kernel row][tap + 4, 16 entries][32 channels] bf16
+constexpr int kDwmRing = 4 * kDwmD + 8;  // ring rows: the waves of a group read rows s - 3 .. s + 4 of a step while rows up to s + 4 D + 4 are requested
 
 // S output quads; LEFT / RIGHT: the strip has an input quad left / right of its output quads (inside the image)
+template <int W> struct DwmGeom {
+    static constexpr int kC = 96 * 56 / W;
+    static constexpr int kSlices = kC / 32;
+    static constexpr int kNQ = (W + 3) / 4;                          // pixel quads of an image row (W = 14: the last one half outside)
+    static constexpr int kStrips = W == 56 ? 4 : (W == 28 ? 2 : 1);  // waves across an image row: 4 4 3 3 / 4 3 / 4 output quads
+    static constexpr int kGroups = 4 / kStrips;                      // (slice, segment) groups per workgroup: the waves of a group share a ring
+    static constexpr int kPitch = kNQ * 256 + 32;                    // ds_read_b32: 32 banks, lanes 0-31 = 4 rows x 8 channel pairs: rows 8 banks apart
+    static constexpr int kGroupLds = (kDwmRing + 1) * kPitch;        // + 1: the dummy row
+    static constexpr size_t kLdsBytes = (size_t)kGroups * kGroupLds;
+    static constexpr int kGRowB = W * kC * 2;
+    static_assert(2 * kLdsBytes <= 160 * 1024, "two workgroups per CU");
+};
 template <int W, int S, int LEFT, int RIGHT>
 struct DwmCfg {
     static constexpr int kC = 96 * 56 / W;
     static constexpr int kQ = S + LEFT + RIGHT;
-    static constexpr int kCols = W == 14 ? 14 : 4 * kQ;           // in-image input columns (W = 14: the last quad is half outside)
-    static constexpr int kPieces = (kCols + 15) / 16;             // 1-KB DMA pieces per row: 16 pixels x 64 B
-    static constexpr int kPitch = kQ * 256 + 32;           // ds_read_b32: 32 banks, lanes 0-31 = 4 rows x 8 channel pairs: rows 8 banks apart
     static constexpr int kStores = 4 * S;
-    static constexpr int kWait = (kDwmD - 1) * (kStores + 4 * kPieces);
-    static constexpr int kGRowB = W * kC * 2;
+    static constexpr int kWait = (kDwmD - 1) * (kStores + 4);        // a step: its stores, then one request per row and wave
     static_assert(kWait <= 63, "vmcnt is a 6-bit counter");
-};
-template <int W> struct DwmGeom {
-    static constexpr int kC = 96 * 56 / W;
-    static constexpr int kSMax = W == 56 ? 3 : 4;
-    static constexpr int kNQ = (W + 3) / 4;
-    static constexpr int kStrips = (kNQ + kSMax - 1) / kSMax;       // 5 (3 3 3 3 2), 2 (4 3), 1 (4)
-    static constexpr int kUnits = kStrips * (kC / 32);
-    static constexpr int kQMax = W == 14 ? 4 : 5;                   // input quads of the widest strip
-    static constexpr int kWaveLds = (kDwmRing + 1) * (kQMax * 256 + 32);      // + 1: the dummy row; the weight table (7 KB) lives in the ring's bytes before the first request
-    static_assert(kWaveLds >= kDwmTabB, "the weight table must fit the ring");
-    static constexpr size_t kLdsBytes = (size_t)4 * kWaveLds;
 };
 
 __device__ __forceinline__ unsigned dwm_lo(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }   // (a.lo, b.lo)
@@ -92,67 +97,26 @@ __device__ __forceinline__ const char* dwm_scalar(const char* p) {
 __device__ __forceinline__ dwm_s4 dwm_op(unsigned r0, unsigned r1) { dwm_u2 v; v.x = r0; v.y = r1; return __builtin_bit_cast(dwm_s4, v); }
 
 template <int W, int S, int LEFT, int RIGHT>
-__device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __restrict__ y, const float* __restrict__ wt,
-                                        const float* __restrict__ bias, char* sink, char* lds, int B, int H, int steps2, int seg,
+__device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __restrict__ y, const char* __restrict__ ops,
+                                        const float* __restrict__ bias, char* sink, char* lds, int piece, int B, int H, int steps, int seg,
                                         int slice, int jt0, unsigned magic, int item) {
     using Cfg = DwmCfg<W, S, LEFT, RIGHT>;
-    constexpr int C = Cfg::kC, Q = Cfg::kQ, kPitch = Cfg::kPitch, R = kDwmRing;
+    using G = DwmGeom<W>;
+    constexpr int C = Cfg::kC, Q = Cfg::kQ, kPitch = G::kPitch, R = kDwmRing;
     const int lane = threadIdx.x & 63, cl = lane >> 2, q = lane & 3;
-    char* const ring = lds;
-    char* const tab = lds;                                 // the weight table lives where the ring will: it is dead before the first request
+    char* const ring = lds;                                // the group's ring: whole image rows of the slice, shared by the waves (strips) of the group
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
     const int ch0 = slice * 32;
     const int col_in0 = 4 * (jt0 - LEFT);
     ACX_DWM_STAMP(0)
 
-    // ---- weights: bf16 table [kh][te = tap + 4][channel], then the lane's operands B[kh][d = kq - jt + 1][set]
-    {
-        // lane -> (channel pair cp, tap group tg): taps tg and tg + 4 of every kernel row, all 14 loads in flight at once (a loop
-        // with a load and an LDS write per iteration paid a memory latency 28 times: half the life of a wave)
-        const int cp = lane & 15, tg = lane >> 4;
-        dwm_f2 v0[7], v1[7];
-#pragma unroll
-        for (int kh = 0; kh < 7; ++kh) {
-            v0[kh] = *reinterpret_cast<const dwm_f2*>(wt + (kh * 7 + tg) * C + ch0 + 2 * cp);
-            v1[kh] = *reinterpret_cast<const dwm_f2*>(wt + (kh * 7 + (tg < 3 ? tg + 4 : tg)) * C + ch0 + 2 * cp);
-        }
-#pragma unroll
-        for (int kh = 0; kh < 7; ++kh) {
-            char* const t = tab + kh * 1024 + cp * 4;
-            *reinterpret_cast<unsigned*>(t + tg * 64) = 0u;
-            *reinterpret_cast<unsigned*>(t + (4 + tg) * 64) = acx_pack_bf16x2(v0[kh].x, v0[kh].y);
-            *reinterpret_cast<unsigned*>(t + (8 + tg) * 64) = tg < 3 ? acx_pack_bf16x2(v1[kh].x, v1[kh].y) : 0u;
-            *reinterpret_cast<unsigned*>(t + (12 + tg) * 64) = 0u;
-        }
-    }
-    const dwm_f2 bv = *reinterpret_cast<const dwm_f2*>(bias + ch0 + 2 * cl);
-    dwm_s4 Bw[7][3][2];
-    {
-        const char* tl = tab + (3 - q) * 64 + cl * 4;
-#pragma unroll
-        for (int kh = 0; kh < 7; ++kh)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                unsigned L[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) L[k] = *reinterpret_cast<const unsigned*>(tl + kh * 1024 + (4 * d + k) * 64);
-                Bw[kh][d][0] = dwm_op(dwm_lo(L[0], L[1]), dwm_lo(L[2], L[3]));
-                Bw[kh][d][1] = dwm_op(dwm_hi(L[0], L[1]), dwm_hi(L[2], L[3]));
-            }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the table has been read: its bytes are ring rows from here on
-    ACX_DWM_STAMP(1)
-
-    // ---- the request side: lane -> (pixel of the piece, 16-byte chunk of its 64-byte channel slice)
-    unsigned voff[Cfg::kPieces];
-    bool vok[Cfg::kPieces];
-#pragma unroll
-    for (int p = 0; p < Cfg::kPieces; ++p) {
-        const int px = p * 16 + (lane >> 2);
-        vok[p] = px < Cfg::kCols;
-        voff[p] = (unsigned)(((col_in0 + (vok[p] ? px : 0)) * C + ch0) * 2 + (lane & 3) * 16);
-    }
-    const int Lrows = 8 * steps2;
+    // ---- the request side: the waves of a group fetch one 1-KB piece (16 pixels x 64 B) of every row each;
+    // lane -> (pixel of the piece, 16-byte chunk of its 64-byte channel slice)
+    const int rpx = piece * 16 + (lane >> 2);
+    const bool vok = rpx < W;
+    const unsigned voff = (unsigned)(((vok ? rpx : 0) * C + ch0) * 2 + (lane & 3) * 16);
+    const unsigned poff = (unsigned)(piece * 1024);
+    const int Lrows = 4 * steps;
     const int vb = seg * Lrows;                            // first output row (stacked) of the segment
     // Two cursors walk the stacked image row by row, in scalar registers (a division per row and request cost 360 cycles of
     // branches per request): clip n, row r of the clip (r >= H: one of the three rows between clips), pointer to the next image row.
@@ -164,51 +128,61 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         const int v0 = vb - 3 + Hp;                        // >= 0
         const int n1 = (int)__umulhi((unsigned)v0, magic);
         qr = v0 - n1 * Hp; qn = n1 - 1;
-        qptr = x + ((long long)qn * H + (qr < H ? qr : H)) * Cfg::kGRowB;
+        qptr = x + ((long long)qn * H + (qr < H ? qr : H)) * G::kGRowB;
     }
-    const char* safe_src = x + (long long)(qn < 0 ? 0 : (qn < B ? qn : B - 1)) * H * Cfg::kGRowB;   // for the requests of non-image rows: a row of this wave's own neighbourhood
+    const char* safe_src = x + (long long)(qn < 0 ? 0 : (qn < B ? qn : B - 1)) * H * G::kGRowB;   // for the requests of non-image rows: a row of this wave's own neighbourhood
     // One request per call, always (the counted waits rely on it).  A row between clips: zeros written by the wave itself, the
     // request re-reads the wave's latest row into the dummy row; a row past the segment's last: the same without the zeros.
     auto request = [&]() {
         const bool need = qleft > 0;
         const bool real = need && qr < H && (unsigned)qn < (unsigned)B;
         const char* const src = real ? qptr : safe_src;
-        const unsigned dst = ring_lds + (real ? qoff : (unsigned)(R * kPitch));
+        const unsigned dst = ring_lds + poff + (real ? qoff : (unsigned)(R * kPitch));
         if (need && !real) {
-#pragma unroll
-            for (int p = 0; p < Cfg::kPieces; ++p)
-                if (vok[p]) *reinterpret_cast<dwm_f4*>(ring + qoff + p * 1024 + lane * 16) = dwm_f4{0.f, 0.f, 0.f, 0.f};
+            if (vok) *reinterpret_cast<dwm_f4*>(ring + qoff + poff + lane * 16) = dwm_f4{0.f, 0.f, 0.f, 0.f};
         }
         safe_src = src;
-        qptr += real ? Cfg::kGRowB : 0;
+        qptr += real ? G::kGRowB : 0;
         qoff = qoff + kPitch == (unsigned)(R * kPitch) ? 0u : qoff + kPitch;
         const bool wrap = qr + 1 == Hp;
         qr = wrap ? 0 : qr + 1;
         qn += wrap ? 1 : 0;
         qleft -= 1;
         if (ACX_DWM_ABLATE == 2) return;
-#pragma unroll
-        for (int p = 0; p < Cfg::kPieces; ++p)
-            if (vok[p]) acx_glds16_s(dwm_scalar(src), voff[p], __builtin_amdgcn_readfirstlane(dst + p * 1024));
+        if (vok) acx_glds16_s(dwm_scalar(src), voff, __builtin_amdgcn_readfirstlane(dst));
     };
     int on, orow;                                          // the output cursor
     char* optr;
     {
         const int n = (int)__umulhi((unsigned)vb, magic);
         on = n; orow = vb - n * Hp;
-        optr = y + ((long long)n * H + (orow < H ? orow : H)) * Cfg::kGRowB;
+        optr = y + ((long long)n * H + (orow < H ? orow : H)) * G::kGRowB;
     }
 
     // W = 14: columns 14 and 15 of every ring row are zeros no request ever writes
-    if constexpr (Cfg::kCols < 4 * Q) {
-        for (int i = lane; i < R * (4 * Q - Cfg::kCols) * 4; i += 64) {
-            const int c = i & 3, px = Cfg::kCols + (i >> 2) % (4 * Q - Cfg::kCols), row = (i >> 2) / (4 * Q - Cfg::kCols);
+    if constexpr (W == 14) {
+        for (int i = lane; i < R * 2 * 4; i += 64) {
+            const int c = i & 3, px = 14 + ((i >> 2) & 1), row = i >> 3;
             *reinterpret_cast<dwm_f4*>(ring + row * kPitch + px * 64 + c * 16) = dwm_f4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    // the first R rows: vb - 3 .. vb + 4 D (everything the steps before the first in-loop request's target read)
+    // the first 4 D + 4 rows: vb - 3 .. vb + 4 D (everything the steps before the first in-loop request's target read)
 #pragma unroll 1
-    for (int i = 0; i < R; ++i) request();
+    for (int i = 0; i < 4 * kDwmD + 4; ++i) request();
+    ACX_DWM_STAMP(1)
+    // ---- weights: the lane's 21 x 2 operands B[kh][d = kq - jt + 1][set], packed once per model in exactly this form
+    // (api.hip, dw_ops: [slice][kh][d][set][lane] x 4 bf16): 42 coalesced 8-byte loads, in flight beside the first rows
+    dwm_s4 Bw[7][3][2];
+    {
+        const char* const ol = ops + (size_t)slice * (42 * 512) + lane * 8;
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) Bw[kh][d][st] = *reinterpret_cast<const dwm_s4*>(ol + ((kh * 3 + d) * 2 + st) * 512);
+    }
+    const dwm_f2 bv = *reinterpret_cast<const dwm_f2*>(bias + ch0 + 2 * cl);
     ACX_DWM_STAMP(2)
 
     // ---- the data side: group g (lane q reads stacked row g - 3 + q), all Q quads, both channel sets.  A group meets kernel row
@@ -219,7 +193,7 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
     auto fetch = [&]() {
         unsigned t = (unsigned)fidx + (unsigned)q;
         t = min(t, t - (unsigned)R);                       // t >= R: wrap (unsigned: t - R is huge otherwise)
-        const char* p = ring + t * kPitch + cl * 4;
+        const char* p = ring + t * kPitch + col_in0 * 64 + cl * 4;
 #pragma unroll
         for (int kq = 0; kq < Q; ++kq)
 #pragma unroll
@@ -236,6 +210,7 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         for (int jt = 0; jt < S; ++jt) { acc[t][jt][0] = b0; acc[t][jt][1] = b1; }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // every wave's pieces of the first rows have landed
     ACX_DWM_STAMP(3)
     fetch();
     ACX_DWM_STAMP(4)
@@ -263,15 +238,18 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
     // a step = four groups; the tile above (Y) is complete after the third and leaves; its registers start the tile below
 #define ACX_DWM_STEP(H_, TAIL_)                                                                                 \
     {                                                                                                           \
+        /* this wave's pieces of the step's rows have landed; behind the barrier everybody's have, and everybody has read \
+           the rows of the step before: their slots take the requests */                                        \
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ACX_DWM_ABLATE == 2 ? 0 : Cfg::kWait) : "memory");           \
+        __builtin_amdgcn_s_barrier();                                                                           \
         ACX_DWM_STORE()                                                                                         \
+        if (!(TAIL_)) { request(); request(); request(); request(); }                                           \
         ACX_DWM_GROUP(4 * (H_) + 0, TAIL_) ACX_DWM_GROUP(4 * (H_) + 1, TAIL_) ACX_DWM_GROUP(4 * (H_) + 2, TAIL_) \
         if (!(TAIL_)) ACX_DWM_GROUP(4 * (H_) + 3, TAIL_)                                                        \
         _Pragma("unroll") for (int jt_ = 0; jt_ < S; ++jt_) {                                                   \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) outp[jt_][i_] = acx_pack_bf16x2(acc[(H_) ^ 1][jt_][0][i_], acc[(H_) ^ 1][jt_][1][i_]); \
             acc[(H_) ^ 1][jt_][0] = b0; acc[(H_) ^ 1][jt_][1] = b1;                                             \
         }                                                                                                       \
-        if (!(TAIL_)) { request(); request(); request(); request(); }                                           \
     }
     // The tile a step completes leaves at the START of the next step, behind that step's wait: a store sits in the same in-order
     // queue as the requests, and the wait of step s + 1 must not stand behind stores issued one step earlier (their
@@ -281,11 +259,11 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                      \
             const bool real_ = ACX_DWM_ABLATE != 5 && live > 1 && orow < H && on < B;                           \
             char* const d_ = real_ ? optr + lane_off : slane;                                                   \
-            optr += real_ ? Cfg::kGRowB : 0;                                                                    \
+            optr += real_ ? G::kGRowB : 0;                                                                    \
             { const bool wrap_ = orow + 1 == Hp; orow = live > 1 ? (wrap_ ? 0 : orow + 1) : orow; on += (live > 1 && wrap_) ? 1 : 0; } \
             _Pragma("unroll") for (int jt_ = 0; jt_ < S; ++jt_) {                                               \
                 char* p_ = d_ + jt_ * 4 * C * 2;                                                                \
-                if (W == 14 && LEFT + jt_ == 3 && q >= 2) p_ = slane + jt_ * 4 * C * 2;                         \
+                if (W == 14 && jt_ == 3 && q >= 2) p_ = slane + jt_ * 4 * C * 2;                         \
                 *reinterpret_cast<unsigned*>(p_) = outp[jt_][i_];                                               \
             }                                                                                                   \
         }                                                                                                       \
@@ -297,13 +275,19 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) outp[jt][i] = 0u;
     int live = 0;                                          // stores 0 and 1 carry nothing (no tile yet; the tile above the segment): sink
+    // steps + 1 steps: the last one is the three groups below the segment's last tile (its kernel rows 4-6), run as an
+    // ordinary step (its requests find nothing left to need; what it adds to the tile below the segment is never stored) --
+    // a second copy of the step for it, and a third for an odd count, put 70 KB of code into stage 0's kernel
+    int left = steps + 1;
+    [[maybe_unused]] int nstamp = 0;
 #pragma unroll 1
-    for (int n2 = 0; n2 < steps2; ++n2) {
+    for (;;) {
         ACX_DWM_STEP(0, false)
+        if (--left == 0) break;
         ACX_DWM_STEP(1, false)
-        ACX_DWM_STAMP(5 + n2)
+        if (--left == 0) break;
+        ACX_DWM_STAMP(5 + nstamp) ++nstamp;
     }
-    ACX_DWM_STEP(0, true)
     ACX_DWM_STORE()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ACX_DWM_STAMP(15)
@@ -314,61 +298,63 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
 }
 
 template <int W>
-__global__ __launch_bounds__(256, 2) void dwconv7_mfma_kernel(const void* __restrict__ x_, void* __restrict__ y_, const float* __restrict__ wt /*[49][C]*/,
-                                                           const float* __restrict__ bias, void* __restrict__ sink_, int B, int H,
-                                                           int steps2 /* pairs of 4-row steps per segment */, int n_items, unsigned magic) {
+__global__ __launch_bounds__(256, 2) void dwconv7_mfma_kernel(const void* __restrict__ x_, void* __restrict__ y_, const void* __restrict__ ops_ /* dw_ops */,
+                                                              const float* __restrict__ bias, void* __restrict__ sink_, int B, int H,
+                                                              int steps /* 4-row steps per segment */, int n_groups, unsigned magic) {
     using G = DwmGeom<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // Consecutive workgroups go to different XCDs (round-robin over 8): logical block = the blockIdx-th in XCD-major order, so
-    // that neighbours in the item order -- the other half of every 128-B line (the next slice), the strip next door (a shared
-    // quad column), the segment below (six shared rows) -- meet in ONE L2 instead of being fetched by two.
+    // that neighbours in the group order -- the other half of every 128-B line (the next slice), the segment below (six shared
+    // rows) -- meet in ONE L2 instead of being fetched by two.
     const int nb = (int)gridDim.x, per = nb >> 3, rem = nb & 7, xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
     const int lblock = xcd * per + (xcd < rem ? xcd : rem) + k;
-    const int item = min(lblock * 4 + wave, n_items - 1);              // a wave past the last item repeats it (identical stores)
-    // slice fastest: a pixel's 64-byte slices (halves of 128-byte lines) are read by neighbouring waves of one workgroup
-    const int unit = item % G::kUnits, seg = item / G::kUnits;
-    const int slice = unit % (G::kC / 32), strip = unit / (G::kC / 32);
+    // a group = (slice, segment), slice fastest; its kStrips waves split the image row (and the requests of every row) between them
+    const int strip = wave % G::kStrips;
+    const int group = min(lblock * G::kGroups + wave / G::kStrips, n_groups - 1);   // a group past the last repeats it (identical stores)
+    const int slice = group % G::kSlices, seg = group / G::kSlices;
+    const int item = group * G::kStrips + strip;
     const char* x = reinterpret_cast<const char*>(x_);
+    const char* wt = reinterpret_cast<const char*>(ops_);
     char* y = reinterpret_cast<char*>(y_);
     char* sink = reinterpret_cast<char*>(sink_) + (size_t)(item % kDwSinkWindows) * kDwSinkWindowBytes;
-    char* lds = smem + wave * G::kWaveLds;
-    const int jt0 = strip * G::kSMax;
+    char* lds = smem + (wave / G::kStrips) * G::kGroupLds;
     if constexpr (W == 56) {
-        if (strip == 0) dwm_run<56, 3, 0, 1>(x, y, wt, bias, sink, lds, B, H, steps2, seg, slice, jt0, magic, item);
-        else if (strip == 4) dwm_run<56, 2, 1, 0>(x, y, wt, bias, sink, lds, B, H, steps2, seg, slice, jt0, magic, item);
-        else dwm_run<56, 3, 1, 1>(x, y, wt, bias, sink, lds, B, H, steps2, seg, slice, jt0, magic, item);
+        if (strip == 0) dwm_run<56, 4, 0, 1>(x, y, wt, bias, sink, lds, 0, B, H, steps, seg, slice, 0, magic, item);
+        else if (strip == 1) dwm_run<56, 4, 1, 1>(x, y, wt, bias, sink, lds, 1, B, H, steps, seg, slice, 4, magic, item);
+        else if (strip == 2) dwm_run<56, 3, 1, 1>(x, y, wt, bias, sink, lds, 2, B, H, steps, seg, slice, 8, magic, item);
+        else dwm_run<56, 3, 1, 0>(x, y, wt, bias, sink, lds, 3, B, H, steps, seg, slice, 11, magic, item);
     } else if constexpr (W == 28) {
-        if (strip == 0) dwm_run<28, 4, 0, 1>(x, y, wt, bias, sink, lds, B, H, steps2, seg, slice, jt0, magic, item);
-        else dwm_run<28, 3, 1, 0>(x, y, wt, bias, sink, lds, B, H, steps2, seg, slice, jt0, magic, item);
+        if (strip == 0) dwm_run<28, 4, 0, 1>(x, y, wt, bias, sink, lds, 0, B, H, steps, seg, slice, 0, magic, item);
+        else dwm_run<28, 3, 1, 0>(x, y, wt, bias, sink, lds, 1, B, H, steps, seg, slice, 4, magic, item);
     } else {
-        dwm_run<14, 4, 0, 0>(x, y, wt, bias, sink, lds, B, H, steps2, seg, slice, jt0, magic, item);
+        dwm_run<14, 4, 0, 0>(x, y, wt, bias, sink, lds, 0, B, H, steps, seg, slice, 0, magic, item);
     }
 }
 
 template <int W>
-static int launch_dw_mfma_w(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H, int target_waves, hipStream_t s) {
+static int launch_dw_mfma_w(const void* x, void* y, const void* wt, const float* bias, void* sink, int B, int H, int target_waves, hipStream_t s) {
     using G = DwmGeom<W>;
     const long long Vt = (long long)B * (H + 3) - 3;
     if ((2 * Vt + 16ll * (H + 3) + 64) * (H + 3) >= 0xffffffffll)      // exactness of v / (H + 3) by multiply-high, up to the rows the last segment requests
         ACX_FAIL(ACX_ERR_SHAPE, "dwconv7: batch too tall for one launch (%d clips of %d rows)", B, H);
-    long long segs = target_waves / G::kUnits;
+    long long segs = target_waves / (G::kStrips * G::kSlices);
     if (segs < 1) segs = 1;
     long long rows = (Vt + segs - 1) / segs;
-    rows = (rows + 7) / 8 * 8;
-    if (rows < 16) rows = 16;
+    rows = (rows + 3) / 4 * 4;
+    if (rows < 8) rows = 8;
     const long long n_seg = (Vt + rows - 1) / rows;
-    const int n_items = (int)(n_seg * G::kUnits);
+    const int n_groups = (int)(n_seg * G::kSlices);
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &dwconv7_mfma_kernel<W>, G::kLdsBytes));
-    launch_kernel(&dwconv7_mfma_kernel<W>, dim3((unsigned)((n_items + 3) / 4)), dim3(256), G::kLdsBytes, s,
-        x, y, wt, bias, sink, B, H, (int)(rows / 8), n_items, (unsigned)(0x100000000ull / (unsigned)(H + 3)) + 1u);
+    launch_kernel(&dwconv7_mfma_kernel<W>, dim3((unsigned)((n_groups + G::kGroups - 1) / G::kGroups)), dim3(256), G::kLdsBytes, s,
+        x, y, wt, bias, sink, B, H, (int)(rows / 4), n_groups, (unsigned)(0x100000000ull / (unsigned)(H + 3)) + 1u);
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
 
 // bf16 activations only (stages 0-2 of set_precision("bf16a")); target_waves as in launch_dwconv_col
-int launch_dwconv_mfma(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H, int W,
+int launch_dwconv_mfma(const void* x, void* y, const void* wt /* BlockW::dw_ops */, const float* bias, void* sink, int B, int H, int W,
                        int target_waves, hipStream_t s) {
     switch (W) {
         case 56: return launch_dw_mfma_w<56>(x, y, wt, bias, sink, B, H, target_waves, s);

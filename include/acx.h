@@ -168,6 +168,11 @@ ACX_API int acx_stem_ln(acx_ctx* ctx, const float* in, int B, int T, float* out,
  * LayerNorm statistics (mean, rstd) of the output (convnext.py:78) into stats (B*H*W, 2). */
 ACX_API int acx_dwconv7(acx_ctx* ctx, int stage, int block, const float* x, float* y, float* stats, int B,
                 int H, int W, void* stream);
+/* K3 on bf16 activations -- the storage type of stages 0-2 under ACX_PREC_BF16_ACT (x, y: NHWC bf16, 2 bytes per element;
+ * any other precision or stage 3: ACX_ERR_STATE).  Matrix-pipe form: weights rounded to bf16, products exact, fp32
+ * accumulation from the bias, one rounding to bf16 at the end (convnext.py:58-60,76). */
+ACX_API int acx_dwconv7_bf16(acx_ctx* ctx, int stage, int block, const uint16_t* x, uint16_t* y, int B, int H, int W,
+                     void* stream);
 /* K3 + K4: whole Block.forward (convnext.py:74-87) on NHWC x, in place: depthwise conv, then LayerNorm + pwconv1 + GELU +
  * pwconv2 + gamma + residual (convnext.py:78-86).  Stages 0-1 (C = 96, 192) run the MLP as ONE fused kernel that keeps
  * the hidden activation in registers; stages 2-3 run two MFMA GEMMs through the hidden scratch.  Set

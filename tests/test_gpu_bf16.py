@@ -128,7 +128,11 @@ def _block_check(ctx16, model16, taps, synth_sd, s, rows):
     act = model16.precision == "bf16a" and s < 3           # stored tensors of this stage are bf16: x in, y, x out
     if act:
         x0 = x0.to(torch.bfloat16).float()                 # what the block reads
-    y = ref_cpu.block_dwconv(synth_sd, s, 0, x0).permute(0, 2, 3, 1)
+    sd_dw = synth_sd
+    if act:                                                # the matrix-pipe depthwise kernel multiplies bf16 weights (dwconv_mfma.hip)
+        sd_dw = dict(synth_sd)
+        sd_dw[p + "dwconv.weight"] = synth_sd[p + "dwconv.weight"].to(torch.bfloat16).float()
+    y = ref_cpu.block_dwconv(sd_dw, s, 0, x0).permute(0, 2, 3, 1)
     if act:
         y = y.to(torch.bfloat16).float()                   # the depthwise conv's output as stored
     # the arithmetic of the bf16 block kernels (mlp_fused_wide_bf16.hip; stage 3: run_mlp_bf16 in api.hip): folds in
@@ -157,6 +161,69 @@ def _block_check(ctx16, model16, taps, synth_sd, s, rows):
         d_f32 = maxdiff(x.permute(0, 3, 1, 2), taps["s%d.b0.out" % s])
         print("stage %d: vs bf16 emulation %.3g, vs fp32 tap %.3g" % (s, d_emu, d_f32))
         assert d_f32 < DRIFT_LAYER_TOL
+
+
+def _dw_bf16(ctx, s, j, xb, B, H, W):
+    y = torch.empty_like(xb)
+    _ffi.check(_ffi.lib().acx_dwconv7_bf16(ctx.handle, s, j, _ffi.ptr(xb), _ffi.ptr(y), B, H, W, sp()))
+    torch.cuda.synchronize()
+    return y
+
+
+# (B, H): one short clip; clip boundaries inside a four-row step; a batch that ends inside a segment; segments of an odd number of
+# steps; the product shape of the stage at 3 clips
+@pytest.mark.parametrize("B,H", [(1, 5), (3, 9), (2, 31), (7, 50), (5, 63), (3, None)])
+@pytest.mark.parametrize("s", [0, 1, 2])
+def test_dwconv_matrix_kernel(ctx16, model16, synth_sd, s, B, H):
+    """acx_dwconv7_bf16 (dwconv_mfma.hip: the depthwise conv of bf16 activations as 4x4x4 bf16 MFMAs, one channel per block)
+    against Block.dwconv (convnext.py:58-60,76) on the same bf16 inputs and bf16-rounded weights, accumulated in fp64: the kernel's
+    products are exact and its accumulation fp32, so a result may differ from the rounded exact sum by ONE bf16 step where the
+    sum sits at a rounding boundary -- and by nothing more, at any shape (clip boundaries, segment ends, image edges)."""
+    if model16.precision != "bf16a":
+        rc = _ffi.lib().acx_dwconv7_bf16(ctx16.handle, s, 0, None, None, 1, 4, 56 >> s, sp())
+        assert rc != 0                                     # no bf16 activations at this precision: refused, not computed
+        return
+    C, W = DIMS[s], 56 >> s
+    H = H if H is not None else 252 >> s
+    g = torch.Generator().manual_seed(4000 + 100 * s + B + H)
+    x = (torch.randn(B, H, W, C, generator=g) * 2.0).to(torch.bfloat16)
+    p = "stages.%d.1." % s
+    w = synth_sd[p + "dwconv.weight"].to(torch.bfloat16).double()
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w, synth_sd[p + "dwconv.bias"].double(), padding=3, groups=C).permute(0, 2, 3, 1)
+    y = _dw_bf16(ctx16, s, 1, x.cuda().contiguous(), B, H, W).cpu()
+    again = _dw_bf16(ctx16, s, 1, x.cuda().contiguous(), B, H, W).cpu()
+    assert torch.equal(y.view(torch.int16), again.view(torch.int16))
+    # y = bf16(fp32 sum), fp32 sum = exact + e with |e| <= 2^-20 sum |x w| (49 products, each added once, fp32 partial sums) and
+    # rounding to bf16 moves a value by at most 2^-8 of itself: |y - exact| <= 2^-8 |exact| + (1 + 2^-8) |e|
+    mag = F.conv2d(x.double().abs().permute(0, 3, 1, 2), w.abs(), synth_sd[p + "dwconv.bias"].double().abs(), padding=3, groups=C).permute(0, 2, 3, 1)
+    err = (y.double() - ref).abs()
+    bound = 2.0 ** -8 * ref.abs() + 1.01 * 2.0 ** -20 * mag
+    worst = float((err / bound).max())
+    exact = float((y == ref.to(torch.bfloat16)).double().mean())
+    print("stage %d B=%d H=%d: %.4f %% of the outputs are the rounded exact sum, worst error %.3f of the bound" % (s, B, H, 100 * exact, worst))
+    assert worst <= 1.0 and exact > 0.99
+
+
+def test_dwconv_matrix_kernel_vs_column_kernel(ctx16, model16, synth_sd):
+    """ACX_DW_MFMA = 0 sends bf16 activations through the column / tile kernels (fp32 weights, 49 FMAs): the two arithmetics differ by the
+    bf16 rounding of the weights only -- 2^-9 relative per tap, far inside the activations' own rounding."""
+    if model16.precision != "bf16a":
+        pytest.skip("bf16 activations only")
+    refresh = _ffi.lib().acx_tuning_refresh
+    s, B = 1, 4
+    C, W, H = DIMS[s], 56 >> s, 252 >> s
+    x = (torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(77)) * 2.0).to(torch.bfloat16).cuda()
+    ym = _dw_bf16(ctx16, s, 0, x, B, H, W).float()
+    os.environ["ACX_DW_MFMA"] = "0"
+    refresh()
+    try:
+        yc = _dw_bf16(ctx16, s, 0, x, B, H, W).float()
+    finally:
+        del os.environ["ACX_DW_MFMA"]
+        refresh()
+    d = maxdiff(ym, yc)
+    print("matrix vs column kernel: max abs diff %.3g at |y| <= %.3g" % (d, float(yc.abs().max())))
+    assert d <= 2.0 ** -6 * float(yc.abs().max())
 
 
 @pytest.mark.parametrize("i", [1, 2, 3])

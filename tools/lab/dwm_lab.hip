@@ -44,7 +44,21 @@ int run_case(int B, int H, int W, int iters, int target_waves, bool check) {
     for (auto& v : hb) v = d(rng);
     std::vector<uint16_t> hx(n);
     for (size_t i = 0; i < n; ++i) hx[i] = to_bf16(d(rng) * 3.f);
-    void *x, *y0, *y1, *sink; float *dw, *db;
+    // the matrix kernel's operand image of the weights (api.hip packs BlockW::dw_ops the same way)
+    std::vector<uint16_t> hops((size_t)(C / 32) * 42 * 64 * 4);
+    for (int sl = 0; sl < C / 32; ++sl)
+        for (int kh = 0; kh < 7; ++kh)
+            for (int d3 = 0; d3 < 3; ++d3)
+                for (int st = 0; st < 2; ++st)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int q = lane & 3, ch = 32 * sl + 2 * (lane >> 2) + st;
+                        for (int k = 0; k < 4; ++k) {
+                            const int tp = 4 * d3 + k - q - 1;
+                            hops[((((size_t)(sl * 7 + kh) * 3 + d3) * 2 + st) * 64 + lane) * 4 + k] = (tp >= 0 && tp < 7) ? to_bf16(hw[(kh * 7 + tp) * C + ch]) : (uint16_t)0;
+                        }
+                    }
+    void *x, *y0, *y1, *sink, *dops; float *dw, *db;
+    CK(hipMalloc(&dops, hops.size() * 2)); CK(hipMemcpy(dops, hops.data(), hops.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&y0, n * 2)); CK(hipMalloc(&y1, n * 2)); CK(hipMalloc(&sink, kDwSinkBytes));
     CK(hipMalloc(&dw, hw.size() * 4)); CK(hipMalloc(&db, hb.size() * 4));
     CK(hipMemcpy(x, hx.data(), n * 2, hipMemcpyHostToDevice));
@@ -52,7 +66,7 @@ int run_case(int B, int H, int W, int iters, int target_waves, bool check) {
     CK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(y0, 0xff, n * 2)); CK(hipMemset(y1, 0xee, n * 2));
     if (launch_dwconv_col(x, y0, dw, db, sink, B, H, W, true, target_waves, nullptr) != ACX_OK) return 1;
-    if (launch_dwconv_mfma(x, y1, dw, db, sink, B, H, W, target_waves, nullptr) != ACX_OK) return 1;
+    if (launch_dwconv_mfma(x, y1, dops, db, sink, B, H, W, target_waves, nullptr) != ACX_OK) return 1;
     CK(hipDeviceSynchronize());
     int bad = 0;
     if (check) {
@@ -95,9 +109,9 @@ int run_case(int B, int H, int W, int iters, int target_waves, bool check) {
             CK(hipEventRecord(e0));
             for (int i = 0; i < iters; ++i) launch_dwconv_col(x, y0, dw, db, sink, B, H, W, true, target_waves, nullptr);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&t_old, e0, e1));
-            for (int i = 0; i < 5; ++i) launch_dwconv_mfma(x, y1, dw, db, sink, B, H, W, target_waves, nullptr);
+            for (int i = 0; i < 5; ++i) launch_dwconv_mfma(x, y1, dops, db, sink, B, H, W, target_waves, nullptr);
             CK(hipEventRecord(e0));
-            for (int i = 0; i < iters; ++i) launch_dwconv_mfma(x, y1, dw, db, sink, B, H, W, target_waves, nullptr);
+            for (int i = 0; i < iters; ++i) launch_dwconv_mfma(x, y1, dops, db, sink, B, H, W, target_waves, nullptr);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&t_new, e0, e1));
         }
     }
@@ -105,7 +119,7 @@ int run_case(int B, int H, int W, int iters, int target_waves, bool check) {
     printf("B=%3d H=%3d W=%2d C=%3d bf16 waves=%4d  %s  column %7.1f us (%5.2f TB/s)  matrix %7.1f us (%5.2f TB/s)\n", B, H, W, C,
            target_waves, check ? (bad ? "WRONG" : "ok") : "unchecked", iters ? t_old * 1e3 / iters : 0.0, iters ? mb / (t_old * 1e3 / iters) : 0.0,
            iters ? t_new * 1e3 / iters : 0.0, iters ? mb / (t_new * 1e3 / iters) : 0.0);
-    hipFree(x); hipFree(y0); hipFree(y1); hipFree(sink); hipFree(dw); hipFree(db);
+    hipFree(x); hipFree(y0); hipFree(y1); hipFree(sink); hipFree(dw); hipFree(db); hipFree(dops);
     return bad;
 }
 
@@ -119,8 +133,8 @@ int main(int argc, char** argv) {
     for (int W : {14, 28, 56}) {
         const int B = 64, H = 252 * W / 56, C = 96 * 56 / W; const size_t n = (size_t)B * H * W * C;
         void *x, *y, *sink; float *dw, *db;
-        CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&y, n * 2)); CK(hipMalloc(&sink, kDwSinkBytes)); CK(hipMalloc(&dw, 49 * C * 4)); CK(hipMalloc(&db, C * 4));
-        CK(hipMemset(x, 0, n * 2)); CK(hipMemset(dw, 0, 49 * C * 4)); CK(hipMemset(db, 0, C * 4));
+        CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&y, n * 2)); CK(hipMalloc(&sink, kDwSinkBytes)); CK(hipMalloc(&dw, (C / 32) * 42 * 512)); CK(hipMalloc(&db, C * 4));
+        CK(hipMemset(x, 0, n * 2)); CK(hipMemset(dw, 0, (C / 32) * 42 * 512)); CK(hipMemset(db, 0, C * 4));
         std::vector<unsigned long long> st(4096 * 16, 0);
         for (int i = 0; i < 4; ++i) launch_dwconv_mfma(x, y, dw, db, sink, B, H, W, waves, nullptr);
         CK(hipDeviceSynchronize());
@@ -131,7 +145,7 @@ int main(int argc, char** argv) {
         unsigned long long t0 = ~0ull, t1 = 0; int items = 0;
         for (int i = 0; i < 4096; ++i) if (st[i * 16 + 15]) { ++items; t0 = std::min(t0, st[i * 16]); t1 = std::max(t1, st[i * 16 + 15]); }
         printf("W=%d: %d waves stamped, first start -> last end %.1f k ticks (100 MHz: 10 ns each)\n  median ticks from the wave's start:", W, items, (t1 - t0) / 1e3);
-        const char* names[16] = {"start", "requests out", "weights built", "rows landed", "window loaded", "pair 0", "pair 1", "pair 2", "pair 3", "pair 4", "pair 5", "pair 6", "pair 7", "pair 8", "pair 9", "end"};
+        const char* names[16] = {"start", "requests out", "weights requested", "rows landed", "first group read", "pair 0", "pair 1", "pair 2", "pair 3", "pair 4", "pair 5", "pair 6", "pair 7", "pair 8", "pair 9", "end"};
         for (int k = 0; k < 16; ++k) {
             std::vector<double> v;
             for (int i = 0; i < 4096; ++i) if (st[i * 16 + 15] && st[i * 16 + k]) v.push_back((double)(st[i * 16 + k] - st[i * 16]));
@@ -159,6 +173,9 @@ int main(int argc, char** argv) {
 #endif
     // odd shapes: one clip, few rows, clip boundaries inside a step, batch ends inside a segment
     bad |= run_case(1, 5, 14, 0, 64, true);
+    bad |= run_case(1, 9, 14, 0, 4096, true);      // 12-row segments: an odd number of steps
+    bad |= run_case(4, 31, 28, 0, 4096, true);
+    bad |= run_case(7, 50, 56, 0, 300, true);
     bad |= run_case(3, 9, 14, 0, 64, true);
     bad |= run_case(2, 31, 28, 0, 64, true);
     bad |= run_case(3, 17, 56, 0, 64, true);
