@@ -128,9 +128,11 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         const int v0 = vb - 3 + Hp;                        // >= 0
         const int n1 = (int)__umulhi((unsigned)v0, magic);
         qr = v0 - n1 * Hp; qn = n1 - 1;
-        qptr = x + ((long long)qn * H + (qr < H ? qr : H)) * G::kGRowB;
+        // (64-bit products are vector instructions even on uniform values: back to scalar registers once, here -- the cursors then
+        // advance by scalar adds; without this every request re-read its pointer out of vector registers)
+        qptr = dwm_scalar(x + ((long long)qn * H + (qr < H ? qr : H)) * G::kGRowB);
     }
-    const char* safe_src = x + (long long)(qn < 0 ? 0 : (qn < B ? qn : B - 1)) * H * G::kGRowB;   // for the requests of non-image rows: a row of this wave's own neighbourhood
+    const char* safe_src = dwm_scalar(x + (long long)(qn < 0 ? 0 : (qn < B ? qn : B - 1)) * H * G::kGRowB);   // for the requests of non-image rows: a row of this wave's own neighbourhood
     // One request per call, always (the counted waits rely on it).  A row between clips: zeros written by the wave itself, the
     // request re-reads the wave's latest row into the dummy row; a row past the segment's last: the same without the zeros.
     auto request = [&]() {
@@ -156,7 +158,7 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
     {
         const int n = (int)__umulhi((unsigned)vb, magic);
         on = n; orow = vb - n * Hp;
-        optr = y + ((long long)n * H + (orow < H ? orow : H)) * G::kGRowB;
+        optr = const_cast<char*>(dwm_scalar(y + ((long long)n * H + (orow < H ? orow : H)) * G::kGRowB));
     }
 
     // W = 14: columns 14 and 15 of every ring row are zeros no request ever writes
@@ -168,7 +170,12 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
     }
     // the first 4 D + 4 rows: vb - 3 .. vb + 4 D (everything the steps before the first in-loop request's target read)
 #pragma unroll 1
-    for (int i = 0; i < 4 * kDwmD + 4; ++i) request();
+    for (int i = 0; i < 4 * kDwmD + 4; ++i) {
+        request();
+#ifdef ACX_DWM_STAMPS_PROLOGUE      // lab: where the start of a wave goes -- stamps 5.. after each of the first requests
+        ACX_DWM_STAMP(5 + i)
+#endif
+    }
     ACX_DWM_STAMP(1)
     // ---- weights: the lane's 21 x 2 operands B[kh][d = kq - jt + 1][set], packed once per model in exactly this form
     // (api.hip, dw_ops: [slice][kh][d][set][lane] x 4 bf16): 42 coalesced 8-byte loads, in flight beside the first rows
@@ -286,7 +293,9 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         if (--left == 0) break;
         ACX_DWM_STEP(1, false)
         if (--left == 0) break;
+#ifndef ACX_DWM_STAMPS_PROLOGUE
         ACX_DWM_STAMP(5 + nstamp) ++nstamp;
+#endif
     }
     ACX_DWM_STORE()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

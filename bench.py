@@ -374,7 +374,9 @@ def profile_rooflines(model, dev, fn, B, precision, n_prof, L=CLIP_SAMPLES):
     mf = sum(v["flops"] for v in merged.values()) / sum(v["ms"] * 1e-3 for v in merged.values()) / 1e12
     out["roofline_all_pointwise"] = {"bound": "mfma", "achieved": mf, "peak": peak, "unit": "TFLOP/s", "frac": mf / peak}
     dw = kernels["dwconv"]
-    out["roofline_dwconv"] = {"kernel": "dwconv7_col_kernel (stages 0-2) + dwconv7_tile_kernel (stage 3)", "bound": "hbm",
+    dw_name = ("dwconv7_mfma_kernel (stages 0-2, bf16 activations) + dwconv7_col_kernel (stage 3)" if precision == "bf16a"
+               else "dwconv7_col_kernel (stages 0-2) + dwconv7_tile_kernel (stage 3)")
+    out["roofline_dwconv"] = {"kernel": dw_name, "bound": "hbm",
                               "achieved": dw["algorithmic_GBs"],
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dw["algorithmic_GBs"] / HBM_PEAK_GBS,
                               "frac_of_copy_rate": dw["algorithmic_GBs"] / HBM_COPY_GBS, "copy_rate": HBM_COPY_GBS,
