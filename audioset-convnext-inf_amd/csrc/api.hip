@@ -397,7 +397,7 @@ static int finalize_impl(acx_ctx* c) {
                             for (int p = 0; p < C / 8; ++p) {
                                 const int pos = p ^ mlp_fused_wide_bf16_swz(C, r);
                                 for (int e = 0; e < 8; ++e)
-                                    w1img[(size_t)r * C + (size_t)pos * 8 + e] = to_bf16(f1[(size_t)(64 * k + r) * C + 8 * p + e]);
+                                    w1img[(size_t)r * C + (size_t)pos * 8 + e] = to_bf16(0.5f * f1[(size_t)(64 * k + r) * C + 8 * p + e]);   // 0.5 W1: the accumulator is z (gelu2h_micro)
                             }
                         // W2 image: row = out channel (128 B = 8 chunks); chunk b = 2 s' + h (s' = k-step 0..3) holds hidden
                         // units 64k + 32(s' >> 1) + 16(s' & 1) + 4h + 8(jj >> 2) + (jj & 3), at position b ^ ((ch >> 1) & 7)
@@ -427,7 +427,7 @@ static int finalize_impl(acx_ctx* c) {
                             for (int p = 0; p < C / 8; ++p) {
                                 const int pos = p ^ mlp_pair_bf16_swz(C, r);
                                 for (int e = 0; e < 8; ++e)
-                                    w1img[(size_t)r * C + (size_t)pos * 8 + e] = to_bf16(f1[(size_t)(32 * k + r) * C + 8 * p + e]);
+                                    w1img[(size_t)r * C + (size_t)pos * 8 + e] = to_bf16(0.5f * f1[(size_t)(32 * k + r) * C + 8 * p + e]);   // 0.5 W1 (gelu2h_micro)
                             }
                         // W2 image: row = out channel (64 B = 4 chunks); chunk b = 2 s' + h (s' = k-step 0..1) holds hidden units
                         // 32k + 16 s' + 4h + 8(jj >> 2) + (jj & 3) -- the order of the producer's accumulator registers -- at

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
 #pragma unroll
     for (int q = 0; q < kB1Iters; ++q) {
         const int i = q * Cfg::kThreads + tid;
-        if (i < C) reinterpret_cast<float4*>(b1s)[i] = b1v[q];
+        if (i < C) reinterpret_cast<float4*>(b1s)[i] = float4{0.5f * b1v[q].x, 0.5f * b1v[q].y, 0.5f * b1v[q].z, 0.5f * b1v[q].w};   // z = 0.5 v (gelu2h_micro)
     }
     if (tid < C / 4) reinterpret_cast<float4*>(b2s)[tid] = b2v;
 
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     for (int q = 0; q < kVar1; ++q) w1off[q] = l31 * (2 * C) + (((2 * q + hh) ^ Cfg::swz1(l31)) << 4);
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp) w2off[sp] = l31 * 128 + (((2 * sp + hh) ^ ((l31 >> 1) & 7)) << 4);
-    const GeluK3 gk = gelu_k3(1.0f, 1.0f);      // X holds the pre-activation itself (no operand scales in this arithmetic): z = 0.5 v
+    const GeluK3 gk = gelu_k2h();      // X holds z = 0.5 v itself: 0.5 W1 in the stream, 0.5 b1 staged (split_math.h, gelu2h_micro)
 
 #define ACX_B8(v_) __builtin_bit_cast(bf16x8, v_)
 #define ACX_FENCE __builtin_amdgcn_sched_barrier(0);
@@ -204,13 +204,13 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
         _Pragma("unroll") for (int sg_ = (from_); sg_ < (to_); ++sg_) {                                         \
             const int mt_ = sg_ / 64, pr_ = (sg_ % 64) / 8, st_ = sg_ % 8;                                      \
             const float ax_ = Xv[mt_][half_][2 * pr_], ay_ = Xv[mt_][half_][2 * pr_ + 1];                       \
-            if (st_ == 0) gelu3_micro<0>(gs, gk, ax_, ay_);                                                     \
-            else if (st_ == 1) gelu3_micro<1>(gs, gk, ax_, ay_);                                                \
-            else if (st_ == 2) gelu3_micro<2>(gs, gk, ax_, ay_);                                                \
-            else if (st_ == 3) gelu3_micro<3>(gs, gk, ax_, ay_);                                                \
-            else if (st_ == 4) gelu3_micro<4>(gs, gk, ax_, ay_);                                                \
-            else if (st_ == 5) gelu3_micro<5>(gs, gk, ax_, ay_);                                                \
-            else if (st_ == 6) gelu3_micro<6>(gs, gk, ax_, ay_);                                                \
+            if (st_ == 0) gelu2h_micro<0>(gs, gk, ax_, ay_);                                                     \
+            else if (st_ == 1) gelu2h_micro<1>(gs, gk, ax_, ay_);                                                \
+            else if (st_ == 2) gelu2h_micro<2>(gs, gk, ax_, ay_);                                                \
+            else if (st_ == 3) gelu2h_micro<3>(gs, gk, ax_, ay_);                                                \
+            else if (st_ == 4) gelu2h_micro<4>(gs, gk, ax_, ay_);                                                \
+            else if (st_ == 5) gelu2h_micro<5>(gs, gk, ax_, ay_);                                                \
+            else if (st_ == 6) gelu2h_micro<6>(gs, gk, ax_, ay_);                                                \
             else un[mt_][half_][pr_] = pack_bf16(gs.qx, gs.qy);                                                 \
         }
 #define ACX_TOUCH1(f_) { asm volatile("" :: "v"(f_)); }
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
         const int piece = wave * (kStreamBytes / 1024 / 8) + p;
         acx_glds16_s(wstream + piece * 1024, lane * 16, acx_lds_addr(smem) + (unsigned)(piece * 1024));
     }
-    for (int i = tid; i < 4 * C; i += 512) b1s[i] = b1[i];
+    for (int i = tid; i < 4 * C; i += 512) b1s[i] = 0.5f * b1[i];        // z = 0.5 v (gelu2h_micro)
     if (tid < C) b2s[tid] = b2[tid];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
     for (int q = 0; q < kVar1; ++q) w1off[q] = l31 * (2 * C) + (((2 * q + hh) ^ Cfg::swz1(l31)) << 4);
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp) w2off[sp] = l31 * 128 + (((2 * sp + hh) ^ ((l31 >> 1) & 7)) << 4);
-    const GeluK3 gk = gelu_k3(1.0f, 1.0f);      // X holds the pre-activation itself (no operand scales in this arithmetic): z = 0.5 v
+    const GeluK3 gk = gelu_k2h();      // X holds z = 0.5 v itself: 0.5 W1 in the stream, 0.5 b1 staged (split_math.h, gelu2h_micro)
 #define ACX_B8(v_) __builtin_bit_cast(bf16x8, v_)
 #define ACX_W1_RD(base_, u_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) & 1) * (32 * 2 * C) + (((u_) >> 1) / kVar1) * (kVar1 * 32) + w1off[((u_) >> 1) % kVar1]))
 #define ACX_W2_RD(base_, u_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) >> 2) * 4096 + w2off[(u_) & 3]))
@@ -615,8 +615,8 @@ __global__ __launch_bounds__(512) void mlp_fused_stat_bf16_kernel(
                 for (int p = 0; p < 4; ++p) {
                     GeluState3 gs;
                     const float ax = X[sp >> 1][2 * (4 * (sp & 1) + p)], ay = X[sp >> 1][2 * (4 * (sp & 1) + p) + 1];
-                    gelu3_micro<0>(gs, gk, ax, ay); gelu3_micro<1>(gs, gk, ax, ay); gelu3_micro<2>(gs, gk, ax, ay); gelu3_micro<3>(gs, gk, ax, ay);
-                    gelu3_micro<4>(gs, gk, ax, ay); gelu3_micro<5>(gs, gk, ax, ay); gelu3_micro<6>(gs, gk, ax, ay);
+                    gelu2h_micro<0>(gs, gk, ax, ay); gelu2h_micro<1>(gs, gk, ax, ay); gelu2h_micro<2>(gs, gk, ax, ay); gelu2h_micro<3>(gs, gk, ax, ay);
+                    gelu2h_micro<4>(gs, gk, ax, ay); gelu2h_micro<5>(gs, gk, ax, ay); gelu2h_micro<6>(gs, gk, ax, ay);
                     un[p] = pack_bf16(gs.qx, gs.qy);
                 }
                 g[sp] = __builtin_bit_cast(f32x4, uint4{un[0], un[1], un[2], un[3]});

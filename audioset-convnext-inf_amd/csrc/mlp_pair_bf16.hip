@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512) void mlp_pair_bf16_kernel(
     // end of an interval: this wave's LDS writes and LDS-DMA pieces (and loads / stores) are done, then the workgroup meets
 #define ACX_ENDINT { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
-    for (int i = tid; i < 4 * C; i += 512) b1s[i] = b1[i];
+    for (int i = tid; i < 4 * C; i += 512) b1s[i] = 0.5f * b1[i];        // z = 0.5 v (gelu2h_micro)
     if (tid < C) b2s[tid] = b2[tid];
     request(0, 1);                                  // interval 0 of the first tile
     ACX_ENDINT
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512) void mlp_pair_bf16_kernel(
         int w1off[kVar1];
 #pragma unroll
         for (int q = 0; q < kVar1; ++q) w1off[q] = l31 * (2 * C) + (((2 * q + hh) ^ Cfg::swz1(l31)) << 4);
-        GeluK3 gk = gelu_k3(1.0f, 1.0f);            // X holds the pre-activation itself: z = 0.5 v
+        GeluK3 gk = gelu_k2h();            // X holds z = 0.5 v itself: 0.5 W1 in the stream, 0.5 b1 staged
         gelu_k3_to_vgprs(gk);                       // two waves per SIMD: a scalar operand costs a vector instruction 2 extra cycles
         f32x4 act[PT][Cfg::kSteps];                 // lane (px = l31, half hh): channels 16 s + 8 hh .. + 7 as 8 bf16
         f32x16 Xa[PT], Xb[PT];                      // pre-activation tiles: one accumulates while the other's GELU is evaluated
@@ -253,13 +253,13 @@ __global__ __launch_bounds__(512) void mlp_pair_bf16_kernel(
 #define ACX_MICRO(Xv_, sg_)                                                                                     \
         {   constexpr int mt_ = (sg_) / 64, pr_ = ((sg_) % 64) / 8, st_ = (sg_) % 8;                            \
             const float ax_ = Xv_[mt_][2 * pr_], ay_ = Xv_[mt_][2 * pr_ + 1];                                   \
-            if constexpr (st_ == 0) gelu3_micro<0>(gst, gk, ax_, ay_);                                          \
-            else if constexpr (st_ == 1) gelu3_micro<1>(gst, gk, ax_, ay_);                                     \
-            else if constexpr (st_ == 2) gelu3_micro<2>(gst, gk, ax_, ay_);                                     \
-            else if constexpr (st_ == 3) gelu3_micro<3>(gst, gk, ax_, ay_);                                     \
-            else if constexpr (st_ == 4) gelu3_micro<4>(gst, gk, ax_, ay_);                                     \
-            else if constexpr (st_ == 5) gelu3_micro<5>(gst, gk, ax_, ay_);                                     \
-            else if constexpr (st_ == 6) gelu3_micro<6>(gst, gk, ax_, ay_);                                     \
+            if constexpr (st_ == 0) gelu2h_micro<0>(gst, gk, ax_, ay_);                                          \
+            else if constexpr (st_ == 1) gelu2h_micro<1>(gst, gk, ax_, ay_);                                     \
+            else if constexpr (st_ == 2) gelu2h_micro<2>(gst, gk, ax_, ay_);                                     \
+            else if constexpr (st_ == 3) gelu2h_micro<3>(gst, gk, ax_, ay_);                                     \
+            else if constexpr (st_ == 4) gelu2h_micro<4>(gst, gk, ax_, ay_);                                     \
+            else if constexpr (st_ == 5) gelu2h_micro<5>(gst, gk, ax_, ay_);                                     \
+            else if constexpr (st_ == 6) gelu2h_micro<6>(gst, gk, ax_, ay_);                                     \
             else un[mt_][pr_] = pair_pack_bf16(gst.qx, gst.qy); }
         auto write_g = [&](const int kc) __attribute__((always_inline)) {
             char* gs = gbase + (kc & 1) * Cfg::kGBytes + lane * 16;

@@ -181,6 +181,33 @@ __device__ __forceinline__ void gelu3_micro(GeluState3& s, const GeluK3 k, const
         s.qx = __builtin_fmaf(__builtin_fabsf(s.zx), s.qx, s.zx); s.qy = __builtin_fmaf(__builtin_fabsf(s.zy), s.qy, s.zy);
     }
 }
+// ---- the GELU of the FUSED bf16 kernels (round 5): degree 2, and z delivered by the matrix pipe -----------------------------------
+// The hidden activation of the bf16 arithmetics is rounded to bf16 (8 significant bits) the moment it exists; a GELU good to 5e-7 is
+// three instructions per element more than that needs.  Q of degree 2 (minimax fit of 0.5 |v| (E - erfc) over [0, 9],
+// tools/lab/fit_gelu.py 2): |gelu error| <= 8.6e-5 absolute -- below half a bf16 step of the result wherever |gelu| > 0.044,
+// an absolute 8.6e-5 below that -- leading coefficient positive, so no clamp, E(0) = 1 exactly.  And the packers store 0.5 W1 (exact
+// in bf16) and the kernels stage 0.5 b1: the accumulator IS z = 0.5 v, the scaling step is gone.  Five vector instructions and one
+// transcendental per element instead of eight and one; same seven-step interface as gelu3_micro (steps 4-6 are empty), result in
+// (s.qx, s.qy).  ax / ay are read by steps 0-3.
+constexpr bool kBf16FusedHalfW1 = true;       // api.hip packs wstream_b / wstream_p with 0.5 W1; the fused bf16 kernels stage 0.5 b1
+__device__ __forceinline__ GeluK3 gelu_k2h() {
+    GeluK3 k;
+    k.zs = 1.0f; k.k3 = 0.f; k.k4 = 0.f;
+    k.k0 = -1.140932559967041f * 2.0f; k.k1 = -0.4882272183895111f * 4.0f; k.k2 = -0.027643846347928047f * 8.0f;    // -c_j / 0.5^(j+1): the unit is z
+    return k;
+}
+template <int STEP>
+__device__ __forceinline__ void gelu2h_micro(GeluState3& s, const GeluK3 k, const float ax, const float ay) {
+    if constexpr (STEP == 0) { s.qx = __builtin_fmaf(__builtin_fabsf(ax), k.k2, k.k1); s.qy = __builtin_fmaf(__builtin_fabsf(ay), k.k2, k.k1); }
+    else if constexpr (STEP == 1) { s.qx = __builtin_fmaf(s.qx, __builtin_fabsf(ax), k.k0); s.qy = __builtin_fmaf(s.qy, __builtin_fabsf(ay), k.k0); }
+    else if constexpr (STEP == 2) {
+        s.qx *= __builtin_fabsf(ax); s.qy *= __builtin_fabsf(ay);
+        s.qx = __builtin_amdgcn_exp2f(s.qx); s.qy = __builtin_amdgcn_exp2f(s.qy);
+    } else if constexpr (STEP == 3) {
+        s.qx = 1.0f - s.qx; s.qy = 1.0f - s.qy;
+        s.qx = __builtin_fmaf(__builtin_fabsf(ax), s.qx, ax); s.qy = __builtin_fmaf(__builtin_fabsf(ay), s.qy, ay);
+    }
+}
 // one value, all at once (epilogues of the bf16 GEMMs)
 __device__ __forceinline__ float gelu3_unit(const float v) {
     const float z = 0.5f * v, a = __builtin_fabsf(z);

@@ -1,5 +1,11 @@
+"""Minimax fit of E(|v|) = exp2(-|v| Q(|v|)) to erfc(|v| / sqrt 2), weighted as the GELU uses it (0.5 |v| (E - erfc)):
+  python tools/lab/fit_gelu.py            degree 4 (split_math.h, gelu3_*: 5.4e-7)
+  python tools/lab/fit_gelu.py 2          degree 2 (split_math.h, gelu2h_micro -- the fused bf16 kernels: 8.6e-5)
+"""
+import sys
 import numpy as np
 from scipy.special import erfc, erf
+DEG = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 from scipy.optimize import least_squares
 v = np.linspace(0, 9, 90001)
 tgt = erfc(v/np.sqrt(2))
@@ -10,7 +16,7 @@ def model(c, v):
     return np.exp2(-v*q)
 m = (v>0)&(v<6)
 y = -np.log2(tgt[m])/v[m]
-c = np.polyfit(v[m], y, 4, w=np.sqrt(tgt[m]))[::-1]
+c = np.polyfit(v[m], y, DEG, w=np.sqrt(tgt[m]))[::-1]
 res = lambda c: 0.5*v*(model(c, v)-tgt)*1e7
 for p in (2,4,8,16,32,64,128,256):
     f = lambda c: np.sign(res(c))*np.abs(res(c)/6)**(p/2)
@@ -24,8 +30,9 @@ def f32(x): return np.asarray(x, np.float64).astype(np.float32).astype(np.float6
 def gelu32(vv):
     z = f32(vv); az = np.abs(z)
     k = [-float(x) for x in c32]
-    q = f32(az*k[4] + k[3])
-    q = f32(q*az + k[2]); q = f32(q*az + k[1]); q = f32(q*az + k[0])
+    q = np.full_like(az, k[DEG])
+    for j in range(DEG - 1, -1, -1):
+        q = f32(q*az + k[j])
     q = f32(q*az)
     e = f32(np.exp2(q))
     r = f32(1.0 - e)
