@@ -240,7 +240,7 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         }                                                                                                       \
         fetch();                                                                                                \
         if (!(TAIL_)) { ACX_DWM_KH(((P_) >> 2) & 1, (P_) & 3) }                                                 \
-        if (((P_) & 3) < 3 && ACX_DWM_ABLATE != 6) { ACX_DWM_KH((((P_) >> 2) & 1) ^ 1, ((P_) & 3) + 4) }        \
+        if constexpr (((P_) & 3) < 3 && ACX_DWM_ABLATE != 6) { ACX_DWM_KH((((P_) >> 2) & 1) ^ 1, ((P_) & 3) + 4) } \
     }
     // a step = four groups; the tile above (Y) is complete after the third and leaves; its registers start the tile below
 #define ACX_DWM_STEP(H_, TAIL_)                                                                                 \

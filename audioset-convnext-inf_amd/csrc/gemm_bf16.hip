@@ -32,9 +32,10 @@ struct GemmBfParams {
     int tiles_n;
 };
 
-__device__ __forceinline__ void lds_dma16_b(const __bf16* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// One 1-KB piece (8 rows x 128 B): scalar base of the tile's first row + a 32-bit offset per lane (its row's distance from that
+// row + its chunk) -- the form whose issue costs one instruction instead of five (split_math.h, acx_glds16_s; round 5).
+__device__ __forceinline__ void lds_dma16_b(const char* sbase, unsigned voff, char* lds_wave_base) {
+    acx_glds16_s(sbase, voff, acx_lds_addr(lds_wave_base));
 }
 
 // EPI: 0 bias -> fp32, 1 bias + GELU -> bf16, 2 bias + residual -> fp32, 3 bias -> bf16 (the downsample conv feeding a stage
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
     static_assert(NW == 8 && A_DMA * 8 * NW == kBM && B_DMA * 8 * NW == BN, "8-wave tiles of 8-row pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
-    char* Bs = smem + 2 * A_TILE;
+    char* Bs = smem + 3 * A_TILE;
+    static_assert(3 * A_TILE + 2 * B_TILE <= (int)kCuLdsBytes, "the rings do not fit the LDS");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -71,43 +73,55 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
     const int n0 = tile_n * BN;
 
     const int prow = lane >> 3, pchunk = lane & 7;
-    const __bf16* a_src[A_DMA];
+    // element index of the first k of row m of A (rows of a tile ascend in memory in both modes: offsets from row m0 are >= 0)
+    auto a_row = [&](long long m) -> long long {
+        if (GATHER) {
+            const int wo = (int)(m % p.Wo);
+            const long long t = m / p.Wo;
+            const int ho = (int)(t % p.Ho);
+            const long long b = t / p.Ho;
+            return ((b * p.H + 2 * ho) * p.W + 2 * wo) * p.Cp;
+        }
+        return m * p.lda;
+    };
+    const long long a_row0 = a_row(m0 < p.M ? m0 : p.M - 1);
+    const char* const a_base = acx_scalar_ptr(p.A + a_row0);
+    unsigned a_src[A_DMA];
 #pragma unroll
     for (int i = 0; i < A_DMA; ++i) {
         const int row = A_DMA * 8 * wave + 8 * i + prow;
         const int chunk = pchunk ^ ((row >> 1) & 7);
         long long m = m0 + row;
         if (m >= p.M) m = p.M - 1;
-        if (GATHER) {
-            const int wo = (int)(m % p.Wo);
-            const long long t = m / p.Wo;
-            const int ho = (int)(t % p.Ho);
-            const long long b = t / p.Ho;
-            a_src[i] = p.A + ((b * p.H + 2 * ho) * p.W + 2 * wo) * p.Cp + 8 * chunk;
-        } else {
-            a_src[i] = p.A + m * p.lda + 8 * chunk;
-        }
+        a_src[i] = (unsigned)((a_row(m) - a_row0 + 8 * chunk) * 2);
     }
-    const __bf16* b_src[B_DMA];
+    const char* const b_base = acx_scalar_ptr(p.Wt + (long long)n0 * p.Kp);
+    unsigned b_src[B_DMA];
 #pragma unroll
     for (int i = 0; i < B_DMA; ++i) {
         const int row = B_DMA * 8 * wave + 8 * i + prow;
         const int chunk = pchunk ^ ((row >> 1) & 7);
-        b_src[i] = p.Wt + (long long)(n0 + row) * p.Kp + 8 * chunk;
+        b_src[i] = (unsigned)((row * p.Kp + 8 * chunk) * 2);
     }
     char* a_dst = As + A_DMA * 8 * wave * kBfRowBytes;
     char* b_dst = Bs + B_DMA * 8 * wave * kBfRowBytes;
-#define ACX_DMA_TILE(k0, buf)                                                                          \
+    auto a_koff = [&](int k0) -> long long {        // element offset of k-tile k0 inside an A row
+        if (GATHER) {
+            const int qd = k0 / p.Cp;
+            return (long long)((qd >> 1) * p.W + (qd & 1)) * p.Cp + (k0 - qd * p.Cp);
+        }
+        return (long long)k0;
+    };
+#define ACX_DMA_A(k0, slot)                                                                            \
     {                                                                                                  \
-        long long koff = (k0);                                                                         \
-        if (GATHER) {                                                                                  \
-            const int qd = (k0) / p.Cp;                                                                \
-            koff = (long long)((qd >> 1) * p.W + (qd & 1)) * p.Cp + ((k0) - qd * p.Cp);                \
-        }                                                                                              \
+        const long long koff = a_koff(k0);                                                             \
         _Pragma("unroll") for (int i = 0; i < A_DMA; ++i)                                              \
-            lds_dma16_b(a_src[i] + koff, a_dst + (buf) * A_TILE + i * 8 * kBfRowBytes);                \
+            lds_dma16_b(a_base + koff * 2, a_src[i], a_dst + (slot) * A_TILE + i * 8 * kBfRowBytes);   \
+    }
+#define ACX_DMA_B(k0, slot)                                                                            \
+    {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < B_DMA; ++i)                                              \
-            lds_dma16_b(b_src[i] + (k0), b_dst + (buf) * B_TILE + i * 8 * kBfRowBytes);                \
+            lds_dma16_b(b_base + (long long)(k0) * 2, b_src[i], b_dst + (slot) * B_TILE + i * 8 * kBfRowBytes); \
     }
 
     f32x16 acc[TM][TN];
@@ -141,12 +155,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
     // The LDS-DMA pieces of the NEXT k-tile are threaded one by one through the MFMAs of this tile's first two groups (A pieces in
     // the first, B pieces in the second), as in gemm.hip: issued as a burst of 7 at the top of the tile they stall the wave for
     // ~700 cycles while its SIMD partner, in lockstep, stalls on its own burst (round 4; the burst form ran 0.29-0.33 of 2.5 PF).
-#define ACX_MFMA_GROUP_DMA(af_, bf_, src_, n_, koff_, dst_)                                            \
+#define ACX_MFMA_GROUP_DMA(af_, bf_, base_, src_, n_, koff_, dst_)                                     \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                               \
             if (i * TN + j < (n_)) {                                                                   \
-                lds_dma16_b(src_[i * TN + j] + (koff_), (dst_) + (i * TN + j) * 8 * kBfRowBytes);      \
+                lds_dma16_b((base_) + (koff_) * 2, src_[i * TN + j], (dst_) + (i * TN + j) * 8 * kBfRowBytes); \
                 __builtin_amdgcn_sched_barrier(0);                                                     \
             }                                                                                          \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af_[i]),    \
@@ -161,8 +175,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
         _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bf_[j]));                \
     }
 
+    // The k loop.  A tile is requested TWO k-tiles ahead (ring of three: in the second MFMA group of tile kt), the weights of tile
+    // kt + 2 as soon as tile kt's slot is free (ring of two: behind tile kt's barrier, in its last MFMA group): the counted wait in
+    // front of a barrier leaves the A pieces just requested in flight.
+    // (Round 5: with both operands one tile ahead the wait in front of every barrier stood for a memory latency that 24 MFMAs per
+    // wave do not cover -- a build without the wait, wrong results, ran pwconv1 / pwconv2 / the downsample convs 20-26 % faster.)
     const int nk = p.Kp / kBfBK;
-    ACX_DMA_TILE(0, 0);
+    ACX_DMA_A(0, 0)
+    ACX_DMA_B(0, 0)
+    ACX_DMA_A((nk > 1 ? 1 : 0) * kBfBK, 1)
+    ACX_DMA_B((nk > 1 ? 1 : 0) * kBfBK, 1)
+    // (the compiler counts the LDS-DMA builtin's loads before a barrier by itself; the inline-asm form is invisible to it)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_DMA + B_DMA) : "memory");
     __syncthreads();
     f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
     {
@@ -171,26 +195,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
         ACX_READ_FRAGS(af0, bf0, ab, bb, 0)
         ACX_READ_FRAGS(af1, bf1, ab, bb, 1)
     }
+    int sa = 0;                                        // A slot of tile kt
     for (int kt = 0; kt + 1 < nk; ++kt) {
-        const char* ab = As + (kt & 1) * A_TILE + a_frag_off;
+        const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
+        const char* ab = As + sa * A_TILE + a_frag_off;
         const char* bb = Bs + (kt & 1) * B_TILE + b_frag_off;
-        const char* abn = As + ((kt + 1) & 1) * A_TILE + a_frag_off;
+        const char* abn = As + sa1 * A_TILE + a_frag_off;
         const char* bbn = Bs + ((kt + 1) & 1) * B_TILE + b_frag_off;
-        const int k1 = (kt + 1) * kBfBK;
-        long long koff1 = k1;
-        if (GATHER) {
-            const int qd = k1 / p.Cp;
-            koff1 = (long long)((qd >> 1) * p.W + (qd & 1)) * p.Cp + (k1 - qd * p.Cp);
-        }
-        char* adn = a_dst + ((kt + 1) & 1) * A_TILE;
-        char* bdn = b_dst + ((kt + 1) & 1) * B_TILE;
+        const int k2 = (kt + 2 < nk ? kt + 2 : nk - 1) * kBfBK;                      // past the end: the last tile once more, into a free slot
+        const long long koff2 = a_koff(k2);
+        char* adn = a_dst + sa2 * A_TILE;
+        char* bdn = b_dst + (kt & 1) * B_TILE;
         __builtin_amdgcn_sched_barrier(0);
-        ACX_MFMA_GROUP_DMA(af0, bf0, a_src, A_DMA, koff1, adn)
+        ACX_MFMA_GROUP(af0, bf0)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af1, bf1)
         ACX_READ_FRAGS(af0, bf0, ab, bb, 2)
         __builtin_amdgcn_sched_barrier(0);
-        ACX_MFMA_GROUP_DMA(af1, bf1, b_src, B_DMA, (long long)k1, bdn)
+        ACX_MFMA_GROUP_DMA(af1, bf1, a_base, a_src, A_DMA, koff2, adn)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af0, bf0)
         ACX_READ_FRAGS(af1, bf1, ab, bb, 3)
@@ -198,16 +220,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
         ACX_MFMA_GROUP(af0, bf0)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af1, bf1)
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_DMA) : "memory");      // this wave's pieces of tile kt + 1 have landed
         __syncthreads();
         ACX_READ_FRAGS(af0, bf0, abn, bbn, 0)
         __builtin_amdgcn_sched_barrier(0);
-        ACX_MFMA_GROUP(af1, bf1)
+        ACX_MFMA_GROUP_DMA(af1, bf1, b_base, b_src, B_DMA, (long long)k2, bdn)
         __builtin_amdgcn_sched_barrier(0);
         ACX_TOUCH(af0, bf0)
         ACX_READ_FRAGS(af1, bf1, abn, bbn, 1)
+        sa = sa1;
     }
     {
-        const char* ab = As + ((nk - 1) & 1) * A_TILE + a_frag_off;
+        const char* ab = As + sa * A_TILE + a_frag_off;
         const char* bb = Bs + ((nk - 1) & 1) * B_TILE + b_frag_off;
         ACX_MFMA_GROUP(af0, bf0)
         __builtin_amdgcn_sched_barrier(0);
@@ -220,7 +244,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmBfParams p)
         ACX_MFMA_GROUP(af0, bf0)
         ACX_MFMA_GROUP(af1, bf1)
     }
-#undef ACX_DMA_TILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the extra request of the last tile must not land in the next workgroup's LDS
+#undef ACX_DMA_A
+#undef ACX_DMA_B
 #undef ACX_READ_FRAGS
 #undef ACX_MFMA_GROUP
 #undef ACX_MFMA_GROUP_DMA
@@ -286,7 +312,7 @@ static int launch_bf_cfg(const GemmBfParams& p0, hipStream_t s) {
     const long long tiles_m = (p.M + kBM - 1) / kBM;
     const long long blocks = tiles_m * p.tiles_n;
     if (blocks > 0x7fffffffLL) ACX_FAIL(ACX_ERR_SHAPE, "gemm_bf16: grid too large");
-    static_assert((size_t)2 * (kBM + BN) * kBfRowBytes <= kCuLdsBytes, "tile does not fit the LDS");
+    static_assert((size_t)(3 * kBM + 2 * BN) * kBfRowBytes <= kCuLdsBytes, "rings do not fit the LDS");
     constexpr size_t lds = kCuLdsBytes;          // all of it: CU-exclusive
     static DeviceOnce once;
     ACX_TRY(set_max_dynamic_lds(once, &gemm_bf16_kernel<kBM, BN, WM, WN, EPI, GATHER>, lds));

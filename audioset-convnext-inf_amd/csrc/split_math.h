@@ -34,6 +34,13 @@ __device__ __forceinline__ void acx_glds16_own_m0(const void* gsrc, unsigned lds
 __device__ __forceinline__ void acx_glds16_s(const void* gbase, unsigned voff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
 }
+// a wave-uniform pointer that came out of vector arithmetic (64-bit products are vector instructions even on uniform values)
+// -> scalar registers, for the "s" operand above
+__device__ __forceinline__ const char* acx_scalar_ptr(const void* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
 // A RUN of pieces that are 1 KB apart in the stream AND in the LDS (a wave's pieces of one segment): the immediate offset of
 // global_load_lds applies to both addresses (verified on the part: offset:1024 moves source and destination by 1 KB), so one
 // M0 write + one 64-bit base serve up to eight pieces (13-bit signed immediate: -4096 .. 3072) and a piece is ONE instruction
