@@ -230,8 +230,8 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
             acc[t_][jt_][0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Ac[kq_][0], Bw[kh_][d_][0], acc[t_][jt_][0], 0, 0, 0); \
             acc[t_][jt_][1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Ac[kq_][1], Bw[kh_][d_][1], acc[t_][jt_][1], 0, 0, 0); \
         }
-    // group P of the eight-group period (P >> 2: which accumulator set is X); TAIL: the groups below the segment's last tile
-#define ACX_DWM_GROUP(P_, TAIL_)                                                                                \
+    // group P of the eight-group period (P >> 2: which accumulator set is X)
+#define ACX_DWM_GROUP(P_)                                                                                       \
     {                                                                                                           \
         dwm_s4 Ac[Q][2];                                                                                        \
         _Pragma("unroll") for (int kq_ = 0; kq_ < Q; ++kq_) {                                                   \
@@ -239,20 +239,19 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
             Ac[kq_][1] = dwm_op(dwm_hi(raw[kq_][0], raw[kq_][1]), dwm_hi(raw[kq_][2], raw[kq_][3]));            \
         }                                                                                                       \
         fetch();                                                                                                \
-        if (!(TAIL_)) { ACX_DWM_KH(((P_) >> 2) & 1, (P_) & 3) }                                                 \
+        ACX_DWM_KH(((P_) >> 2) & 1, (P_) & 3)                                                                   \
         if constexpr (((P_) & 3) < 3 && ACX_DWM_ABLATE != 6) { ACX_DWM_KH((((P_) >> 2) & 1) ^ 1, ((P_) & 3) + 4) } \
     }
     // a step = four groups; the tile above (Y) is complete after the third and leaves; its registers start the tile below
-#define ACX_DWM_STEP(H_, TAIL_)                                                                                 \
+#define ACX_DWM_STEP(H_)                                                                                        \
     {                                                                                                           \
         /* this wave's pieces of the step's rows have landed; behind the barrier everybody's have, and everybody has read \
            the rows of the step before: their slots take the requests */                                        \
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ACX_DWM_ABLATE == 2 ? 0 : Cfg::kWait) : "memory");           \
         __builtin_amdgcn_s_barrier();                                                                           \
         ACX_DWM_STORE()                                                                                         \
-        if (!(TAIL_)) { request(); request(); request(); request(); }                                           \
-        ACX_DWM_GROUP(4 * (H_) + 0, TAIL_) ACX_DWM_GROUP(4 * (H_) + 1, TAIL_) ACX_DWM_GROUP(4 * (H_) + 2, TAIL_) \
-        if (!(TAIL_)) ACX_DWM_GROUP(4 * (H_) + 3, TAIL_)                                                        \
+        request(); request(); request(); request();                                                             \
+        ACX_DWM_GROUP(4 * (H_) + 0) ACX_DWM_GROUP(4 * (H_) + 1) ACX_DWM_GROUP(4 * (H_) + 2) ACX_DWM_GROUP(4 * (H_) + 3) \
         _Pragma("unroll") for (int jt_ = 0; jt_ < S; ++jt_) {                                                   \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) outp[jt_][i_] = acx_pack_bf16x2(acc[(H_) ^ 1][jt_][0][i_], acc[(H_) ^ 1][jt_][1][i_]); \
             acc[(H_) ^ 1][jt_][0] = b0; acc[(H_) ^ 1][jt_][1] = b1;                                             \
@@ -289,9 +288,9 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
     [[maybe_unused]] int nstamp = 0;
 #pragma unroll 1
     for (;;) {
-        ACX_DWM_STEP(0, false)
+        ACX_DWM_STEP(0)
         if (--left == 0) break;
-        ACX_DWM_STEP(1, false)
+        ACX_DWM_STEP(1)
         if (--left == 0) break;
 #ifndef ACX_DWM_STAMPS_PROLOGUE
         ACX_DWM_STAMP(5 + nstamp) ++nstamp;
