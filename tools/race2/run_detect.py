@@ -1,6 +1,7 @@
 """Sensitive detector (tools/race2/detector.hip, packed and scalar builds) next to a list of aggressors.
     python tools/race2/run_detect.py AGGRESSOR [AGGRESSOR ...]
-    aggressors: none down1..3 block0..3 dw0..3 burnN:BLOCKS (N = 1, 4, 6 independent accumulators)"""
+    aggressors: none down1..3 block0..3 dw0..3 dwm0..2 burnN:BLOCKS (N = 1, 4, 6 independent accumulators)
+    dwm: the matrix-pipe depthwise kernel of bf16 activations (needs ACX_PRECISION=bf16a)"""
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -46,6 +47,12 @@ def make_load(what):
         def f():
             for _ in range(4): lib.acx_block(h, s, 0, _ffi.ptr(x), B, HS[s], WS[s], _ffi.ptr(scr), need.value, null_sp)
         f.keep = (x, scr)
+        return f
+    if what.startswith("dwm"):
+        x = torch.randn(B, HS[s], WS[s], DIMS[s], device="cuda").to(torch.bfloat16); y = torch.empty_like(x)
+        def f():
+            for _ in range(12): _ffi.check(lib.acx_dwconv7_bf16(h, s, 0, _ffi.ptr(x), _ffi.ptr(y), B, HS[s], WS[s], null_sp))
+        f.keep = (x, y)
         return f
     if what.startswith("dw"):
         x = torch.randn(B, HS[s], WS[s], DIMS[s], device="cuda"); y = torch.empty_like(x)
