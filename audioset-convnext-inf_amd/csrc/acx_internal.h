@@ -229,6 +229,7 @@ struct Tuning {
     std::atomic<int> fail_sub{-1};     // acx_test_fail_sub(i): acx_forward reports a failure after queueing sub-batch i (error-path tests; never read from the environment)
     std::atomic<int> wide_pers{0};     // ACX_WIDE_PERSIST: 1 = persistent wide fused MLP wherever it exists, 2 = never; 0 = by launch size
     std::atomic<int> bf16_pair{-1};    // ACX_BF16_PAIR = 1: the paired (producer / consumer) fused bf16 MLP instead of the ring kernels (C = 192, 384); default: ring
+    std::atomic<int> dwm_waves{0};     // ACX_DWM_WAVES = 2..9: the matrix-pipe depthwise launch asks for that many waves per CU of its share (0: 8 = two per SIMD)
     std::atomic<int> dw_mfma{-1};      // ACX_DW_MFMA = 0: bf16 activations go through the column / tile depthwise kernels instead of the matrix-pipe kernel (A/B timing: other bits)
     std::atomic<int> dw_stream{-1};    // ACX_DW_STREAM = 0 | 1: forces the tile / column-streaming depthwise kernels (-1: by launch size)
 };

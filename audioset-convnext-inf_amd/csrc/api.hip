@@ -29,6 +29,7 @@ void tuning_reload() {
     t.gemm_32x32.store(digit("ACX_GEMM_32X32", "1", 0), std::memory_order_relaxed);
     t.dw_stream.store(digit("ACX_DW_STREAM", "01", -1), std::memory_order_relaxed);
     t.dw_mfma.store(digit("ACX_DW_MFMA", "01", -1), std::memory_order_relaxed);
+    t.dwm_waves.store(digit("ACX_DWM_WAVES", "23456789", 0), std::memory_order_relaxed);
     t.bf16_pair.store(digit("ACX_BF16_PAIR", "01", -1), std::memory_order_relaxed);
 }
 

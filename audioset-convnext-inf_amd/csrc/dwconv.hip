@@ -695,7 +695,8 @@ int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, fl
         if (act_bf16 && c && c->d_dw_sink && w.dw_ops && C == 96 * 56 / (W > 0 ? W : 1) && W != 7 && tuning().dw_mfma.load(std::memory_order_relaxed) != 0) {
             int cus = 0;
             ACX_TRY(cu_count_of_current_device(&cus));
-            return launch_dwconv_mfma(x, y, w.dw_ops, w.dwb, c->d_dw_sink, B, H, W, 8 * cus / inflight_ways(), s);
+            const int per_cu = tuning().dwm_waves.load(std::memory_order_relaxed);
+            return launch_dwconv_mfma(x, y, w.dw_ops, w.dwb, c->d_dw_sink, B, H, W, (per_cu ? per_cu : 8) * cus / inflight_ways(), s);
         }
         if (C == 96 * 56 / (W > 0 ? W : 1) && !(W == 7 && act_bf16) && use_col_kernel(c, B, H, W, act_bf16, &target_waves)) {
             rc = launch_dwconv_col(x, y, w.dw, w.dwb, c->d_dw_sink, B, H, W, act_bf16, target_waves, s);
