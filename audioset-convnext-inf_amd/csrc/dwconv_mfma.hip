@@ -217,7 +217,7 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         for (int jt = 0; jt < S; ++jt) { acc[t][jt][0] = b0; acc[t][jt][1] = b1; }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // every wave's pieces of the first rows have landed
+    if constexpr (G::kStrips > 1) __builtin_amdgcn_s_barrier();      // every wave's pieces of the first rows have landed (W = 14: a group is one wave, its ring its own)
     ACX_DWM_STAMP(3)
     fetch();
     ACX_DWM_STAMP(4)
@@ -248,7 +248,7 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         /* this wave's pieces of the step's rows have landed; behind the barrier everybody's have, and everybody has read \
            the rows of the step before: their slots take the requests */                                        \
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ACX_DWM_ABLATE == 2 ? 0 : Cfg::kWait) : "memory");           \
-        __builtin_amdgcn_s_barrier();                                                                           \
+        if constexpr (G::kStrips > 1) __builtin_amdgcn_s_barrier();                                             \
         ACX_DWM_STORE()                                                                                         \
         request(); request(); request(); request();                                                             \
         ACX_DWM_GROUP(4 * (H_) + 0) ACX_DWM_GROUP(4 * (H_) + 1) ACX_DWM_GROUP(4 * (H_) + 2) ACX_DWM_GROUP(4 * (H_) + 3) \
