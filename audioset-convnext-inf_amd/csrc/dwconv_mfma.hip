@@ -208,7 +208,6 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         fidx = fidx + 1 == R ? 0 : fidx + 1;
     };
     const unsigned lane_off = (unsigned)(((4 * jt0 + q) * C + ch0 + 2 * cl) * 2);
-    char* const slane = sink + lane_off;
     const dwm_f4 b0 = {bv.x, bv.x, bv.x, bv.x}, b1 = {bv.y, bv.y, bv.y, bv.y};
     dwm_f4 acc[2][S][2];
 #pragma unroll
@@ -227,8 +226,11 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         _Pragma("unroll") for (int d_ = 0; d_ < 3; ++d_) {                                                      \
             const int kq_ = jt_ + d_ - 1 + LEFT;                                                                \
             if (kq_ < 0 || kq_ >= Q) continue;                                                                  \
-            acc[t_][jt_][0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Ac[kq_][0], Bw[kh_][d_][0], acc[t_][jt_][0], 0, 0, 0); \
-            acc[t_][jt_][1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Ac[kq_][1], Bw[kh_][d_][1], acc[t_][jt_][1], 0, 0, 0); \
+            /* a tile's first instruction (kernel row 0, its first input quad) takes the bias as its C operand: no 32 register \
+               moves per step to start the accumulators from */                                                 \
+            const bool first_ = (kh_) == 0 && d_ == (jt_ - 1 + LEFT >= 0 ? 0 : 1);                              \
+            acc[t_][jt_][0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Ac[kq_][0], Bw[kh_][d_][0], first_ ? b0 : acc[t_][jt_][0], 0, 0, 0); \
+            acc[t_][jt_][1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Ac[kq_][1], Bw[kh_][d_][1], first_ ? b1 : acc[t_][jt_][1], 0, 0, 0); \
         }
     // group P of the eight-group period (P >> 2: which accumulator set is X)
 #define ACX_DWM_GROUP(P_)                                                                                       \
@@ -254,7 +256,6 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
         ACX_DWM_GROUP(4 * (H_) + 0) ACX_DWM_GROUP(4 * (H_) + 1) ACX_DWM_GROUP(4 * (H_) + 2) ACX_DWM_GROUP(4 * (H_) + 3) \
         _Pragma("unroll") for (int jt_ = 0; jt_ < S; ++jt_) {                                                   \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) outp[jt_][i_] = acx_pack_bf16x2(acc[(H_) ^ 1][jt_][0][i_], acc[(H_) ^ 1][jt_][1][i_]); \
-            acc[(H_) ^ 1][jt_][0] = b0; acc[(H_) ^ 1][jt_][1] = b1;                                             \
         }                                                                                                       \
     }
     // The tile a step completes leaves at the START of the next step, behind that step's wait: a store sits in the same in-order
@@ -264,13 +265,14 @@ __device__ __forceinline__ void dwm_run(const char* __restrict__ x, char* __rest
     {                                                                                                           \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                      \
             const bool real_ = ACX_DWM_ABLATE != 5 && live > 1 && orow < H && on < B;                           \
-            char* const d_ = real_ ? optr + lane_off : slane;                                                   \
-            optr += real_ ? G::kGRowB : 0;                                                                    \
+            /* scalar base + 32-bit lane offset: the address costs no vector instruction; W = 14: the two lanes of the last \
+               quad that lie outside the image are masked out of the store */                                   \
+            char* const d_ = real_ ? optr : sink;                                                               \
+            optr += real_ ? G::kGRowB : 0;                                                                      \
             { const bool wrap_ = orow + 1 == Hp; orow = live > 1 ? (wrap_ ? 0 : orow + 1) : orow; on += (live > 1 && wrap_) ? 1 : 0; } \
             _Pragma("unroll") for (int jt_ = 0; jt_ < S; ++jt_) {                                               \
-                char* p_ = d_ + jt_ * 4 * C * 2;                                                                \
-                if (W == 14 && jt_ == 3 && q >= 2) p_ = slane + jt_ * 4 * C * 2;                         \
-                *reinterpret_cast<unsigned*>(p_) = outp[jt_][i_];                                               \
+                if (!(W == 14 && jt_ == 3 && q >= 2))                                                           \
+                    *reinterpret_cast<unsigned*>(d_ + (size_t)(lane_off + (unsigned)(jt_ * 4 * C * 2))) = outp[jt_][i_]; \
             }                                                                                                   \
         }                                                                                                       \
         live += 1;                                                                                              \
