@@ -226,6 +226,28 @@ def test_dwconv_matrix_kernel_vs_column_kernel(ctx16, model16, synth_sd):
     assert d <= 2.0 ** -6 * float(yc.abs().max())
 
 
+def test_dwconv_matrix_kernel_segmentation_is_invisible(ctx16, model16):
+    """The matrix-pipe depthwise kernel cuts the stacked batch into segments by the number of waves it is asked to fill
+    (ACX_DWM_WAVES per CU; 8 by default, halved per sub-batch in flight): an output's arithmetic -- bias, then kernel rows 0-3 of its
+    tile's X phase, then 4-6 of its Y phase, input quads left to right -- must not depend on where the segments fall."""
+    if model16.precision != "bf16a":
+        pytest.skip("bf16 activations only")
+    refresh = _ffi.lib().acx_tuning_refresh
+    s, B = 2, 5
+    C, W, H = DIMS[s], 56 >> s, 252 >> s
+    x = (torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(99)) * 2.0).to(torch.bfloat16).cuda()
+    ref = _dw_bf16(ctx16, s, 2, x, B, H, W)
+    try:
+        for v in ("2", "5", "9"):
+            os.environ["ACX_DWM_WAVES"] = v
+            refresh()
+            got = _dw_bf16(ctx16, s, 2, x, B, H, W)
+            assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), v
+    finally:
+        os.environ.pop("ACX_DWM_WAVES", None)
+        refresh()
+
+
 @pytest.mark.parametrize("i", [1, 2, 3])
 def test_downsample_bf16(ctx16, taps, synth_sd, i):
     Ci, Co = DIMS[i - 1], DIMS[i]
