@@ -49,6 +49,7 @@ SIGNATURES = {
     "acx_comm_info": (_c_int, [_vp, _pint, _pint]),
     "acx_pcm16_to_f32": (_c_int, [_vp, _vp, _c_i64, _vp]),
     "acx_frontend_info": (_c_int, [_vp, _pint, ctypes.POINTER(ctypes.c_float), _pint]),
+    "acx_set_frontend": (_c_int, [_vp, _c_int]),
     "acx_tuning_refresh": (_c_int, []),
     "acx_test_fail_sub": (_c_int, [_c_int]),
     "acx_profile_enable": (_c_int, [_vp, _c_int]),
@@ -101,6 +102,7 @@ def stream_ptr(device):
 
 
 PRECISIONS = {"fp32": 0, "bf16": 1, "fp32_split": 2, "bf16a": 3}
+FRONTENDS = {"auto": 0, "dense": 1}      # enum acx_frontend
 
 
 class Context:
@@ -174,6 +176,11 @@ class Context:
         out = torch.empty((w.value * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         check(lib().acx_allgather(self._h, ptr(local), ptr(out), local.numel() * local.element_size(), stream_ptr(local.device)))
         return out
+
+    def set_frontend(self, mode):
+        """"auto" (FFT kernel when the stored STFT buffers are window x DFT) or "dense" (always the reference's dense DFT
+        contraction with the stored weights: the parity mode, acx.h acx_set_frontend)."""
+        check(lib().acx_set_frontend(self._h, FRONTENDS[mode]))
 
     def frontend_info(self):
         """{"dense_dft": bool, "stft_deviation": float, "mel_taps": int} -- how acx_finalize evaluates the frontend."""

@@ -127,7 +127,6 @@ struct BlockW {          // one ConvNeXt Block (convnext.py:44-87), kernel layou
     uint16_t* w2s = nullptr; // split mode: gamma * pwconv2 in S16 form, scaled by w2s_scale
     uint16_t* wpack_s = nullptr; // split mode, C = 96/192: chunk-major [W1c | W2c] S16 image (mlp_fused_split.hip)
     uint16_t* wstream_b = nullptr; // bf16 mode: the same segment stream in bf16, chunks of 64 hidden units (mlp_fused_wide_bf16.hip)
-    uint16_t* wstream_p = nullptr; // bf16 modes, C = 192 / 384: 32-hidden-unit segments in the consumption order of mlp_pair_bf16.hip
     uint16_t* wstream_s = nullptr; // split mode, C = 384: segment stream in consumption order, LDS image order (mlp_fused_wide.hip)
     float w1s_scale = 1.f, w2s_scale = 1.f;
     float hid_scale = 1.f;   // split mode: power-of-two scale of the S16 hidden activation (GELU output)
@@ -168,6 +167,7 @@ struct acx_ctx {
     float* d_bn_shift = nullptr;  // [224]
     // dense-DFT fallback (STFT buffers that are not window x DFT: the two Conv1d are evaluated as one GEMM, convnext.py:179-187)
     bool dense_stft = false;
+    bool force_dense_stft = false; // acx_set_frontend(ACX_FRONTEND_DENSE)
     float stft_deviation = 0.f;   // max |stored - hann x DFT| found at acx_finalize
     float* d_stft_w = nullptr;    // [kDenseN][1024]: rows 0..512 conv_real, 513..1025 conv_imag, the rest zero
     float* d_stft_zero = nullptr; // [kDenseN] zero bias
@@ -228,7 +228,6 @@ struct Tuning {
     std::atomic<int> gemm_32x32{0};    // ACX_GEMM_32X32 = 1: the 32x32x16 form of the split GEMM
     std::atomic<int> fail_sub{-1};     // acx_test_fail_sub(i): acx_forward reports a failure after queueing sub-batch i (error-path tests; never read from the environment)
     std::atomic<int> wide_pers{0};     // ACX_WIDE_PERSIST: 1 = persistent wide fused MLP wherever it exists, 2 = never; 0 = by launch size
-    std::atomic<int> bf16_pair{-1};    // ACX_BF16_PAIR = 1: the paired (producer / consumer) fused bf16 MLP instead of the ring kernels (C = 192, 384); default: ring
     std::atomic<int> dwm_waves{0};     // ACX_DWM_WAVES = 2..9: the matrix-pipe depthwise launch asks for that many waves per CU of its share (0: 8 = two per SIMD)
     std::atomic<int> dw_mfma{-1};      // ACX_DW_MFMA = 0: bf16 activations go through the column / tile depthwise kernels instead of the matrix-pipe kernel (A/B timing: other bits)
     std::atomic<int> dw_stream{-1};    // ACX_DW_STREAM = 0 | 1: forces the tile / column-streaming depthwise kernels (-1: by launch size)
@@ -335,12 +334,6 @@ int launch_mlp_fused_wide(acx_ctx* c, const BlockW& w, int C, const float* y, fl
                           void* ln_out = nullptr);
 // bf16 arithmetic (mlp_fused_wide_bf16.hip): the fused block MLP for C = 96 / 192 / 384; ln_out (with row stride ld_out
 // bf16 elements) receives LayerNorm(x_new) as bf16 rows INSTEAD of x when non-null
-bool mlp_pair_bf16_supported(int C);          // mlp_pair_bf16.hip: producer / consumer wave pairs (C = 192, 384)
-int mlp_pair_bf16_swz(int C, int row);
-int mlp_pair_bf16_pos_w1(int C, int k);
-int mlp_pair_bf16_pos_w2(int C, int j);
-int launch_mlp_pair_bf16(acx_ctx* c, const BlockW& w, int C, const void* y, void* x, long long M, hipStream_t s,
-                         void* ln_out, int ld_out, bool act_bf16);
 bool mlp_fused_wide_bf16_supported(int C);
 int mlp_fused_wide_bf16_swz(int C, int row);
 int launch_mlp_fused_wide_bf16(acx_ctx* c, const BlockW& w, int C, const void* y, void* x, long long M, hipStream_t s,

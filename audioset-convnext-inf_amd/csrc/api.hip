@@ -30,7 +30,6 @@ void tuning_reload() {
     t.dw_stream.store(digit("ACX_DW_STREAM", "01", -1), std::memory_order_relaxed);
     t.dw_mfma.store(digit("ACX_DW_MFMA", "01", -1), std::memory_order_relaxed);
     t.dwm_waves.store(digit("ACX_DWM_WAVES", "23456789", 0), std::memory_order_relaxed);
-    t.bf16_pair.store(digit("ACX_BF16_PAIR", "01", -1), std::memory_order_relaxed);
 }
 
 void set_error(const char* fmt, ...) {
@@ -233,7 +232,7 @@ static int finalize_impl(acx_ctx* c) {
     std::vector<float> hann;
     const double dev = stft_deviation_from_dft(c, &hann);
     c->stft_deviation = (float)dev;
-    c->dense_stft = !(dev <= 2e-6);
+    c->dense_stft = c->force_dense_stft || !(dev <= 2e-6);
     c->d_stft_w = nullptr; c->d_stft_zero = nullptr;
     if (c->dense_stft) {
         std::vector<float> w((size_t)kDenseN * kNFFT, 0.f);
@@ -414,37 +413,6 @@ static int finalize_impl(acx_ctx* c) {
                             }
                     }
                     ACX_TRY(upload(c, st, &bw.wstream_b));
-                }
-                if (c->use_fused_mlp && mlp_pair_bf16_supported(C)) {
-                    // mlp_pair_bf16.hip: segments of 32 hidden units (64 C bytes each) at the stream positions the kernel
-                    // consumes them in (W1(k) in interval k, W2(j) in interval j + 2; period 2n), each in LDS image order.
-                    const int nch = 4 * C / 32;
-                    const size_t seg = (size_t)32 * C;                   // uint16 elements per segment
-                    std::vector<uint16_t> st((size_t)2 * nch * seg);
-                    for (int k = 0; k < nch; ++k) {
-                        // W1 image: row r = hidden unit 32k + r (2 C bytes = C/8 chunks of 8 channels), chunk p at p ^ swz(r)
-                        uint16_t* w1img = st.data() + (size_t)mlp_pair_bf16_pos_w1(C, k) * seg;
-                        for (int r = 0; r < 32; ++r)
-                            for (int p = 0; p < C / 8; ++p) {
-                                const int pos = p ^ mlp_pair_bf16_swz(C, r);
-                                for (int e = 0; e < 8; ++e)
-                                    w1img[(size_t)r * C + (size_t)pos * 8 + e] = to_bf16(0.5f * f1[(size_t)(32 * k + r) * C + 8 * p + e]);   // 0.5 W1 (gelu2h_micro)
-                            }
-                        // W2 image: row = out channel (64 B = 4 chunks); chunk b = 2 s' + h (s' = k-step 0..1) holds hidden units
-                        // 32k + 16 s' + 4h + 8(jj >> 2) + (jj & 3) -- the order of the producer's accumulator registers -- at
-                        // position b ^ ((ch >> 2) & 3)
-                        uint16_t* w2img = st.data() + (size_t)mlp_pair_bf16_pos_w2(C, k) * seg;
-                        for (int ch = 0; ch < C; ++ch)
-                            for (int b = 0; b < 4; ++b) {
-                                const int sp = b >> 1, h = b & 1;
-                                const int pos = b ^ ((ch >> 2) & 3);
-                                for (int jj = 0; jj < 8; ++jj) {
-                                    const int u = 32 * k + 16 * sp + 4 * h + 8 * (jj >> 2) + (jj & 3);
-                                    w2img[(size_t)ch * 32 + (size_t)pos * 8 + jj] = to_bf16(f2[(size_t)ch * 4 * C + u]);
-                                }
-                            }
-                    }
-                    ACX_TRY(upload(c, st, &bw.wstream_p));
                 }
             }
             if (c->precision == ACX_PREC_F32_SPLIT) {
@@ -629,9 +597,6 @@ static int run_block(acx_ctx* c, int s, int j, float* x, float* y, float* hidden
     if (is_bf16(c)) {
         const bool ab = act_bf16(c, s);         // x and y of this stage are bf16 tensors in HBM
         ACX_TRY(launch_dwconv(c, bw, C, x, y, nullptr, B, H, Wd, st, ab));
-        // (the producer / consumer form of mlp_pair_bf16.hip: measured, not the default -- DESIGN.md 3g)
-        if (c->use_fused_mlp && bw.wstream_p && tuning().bf16_pair.load(std::memory_order_relaxed) == 1)
-            return launch_mlp_pair_bf16(c, bw, C, y, x, M, st, ln_out, pad64(C), ab);
         if (c->use_fused_mlp && bw.wstream_b) return launch_mlp_fused_wide_bf16(c, bw, C, y, x, M, st, ln_out, pad64(C), ab);
         if (ab) ACX_FAIL(ACX_ERR_STATE, "run_block: bf16 activations need the fused block kernel (stage %d)", s);
         if (ln_out) ACX_FAIL(ACX_ERR_STATE, "run_block: LayerNorm output requested from a two-GEMM stage");
@@ -806,6 +771,15 @@ int acx_set_precision(acx_ctx* c, int precision) {
     if (precision != ACX_PREC_F32 && precision != ACX_PREC_BF16 && precision != ACX_PREC_F32_SPLIT && precision != ACX_PREC_BF16_ACT) ACX_FAIL(ACX_ERR_ARG, "acx_set_precision: unknown precision %d", precision);
     if (precision != c->precision) { c->precision = precision; c->finalized = false; }
     return ACX_OK;
+}
+
+int acx_set_frontend(acx_ctx* c, int mode) {
+    if (!c) ACX_FAIL(ACX_ERR_ARG, "null context");
+    if (mode != ACX_FRONTEND_AUTO && mode != ACX_FRONTEND_DENSE) ACX_FAIL(ACX_ERR_ARG, "acx_set_frontend: unknown mode %d", mode);
+    const bool dense = mode == ACX_FRONTEND_DENSE;
+    if (dense == c->force_dense_stft) return ACX_OK;
+    c->force_dense_stft = dense;
+    return c->finalized ? acx_finalize(c) : ACX_OK;
 }
 
 int acx_num_frames(int64_t L, int* T) {

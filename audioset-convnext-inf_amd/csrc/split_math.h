@@ -196,7 +196,7 @@ __device__ __forceinline__ void gelu3_micro(GeluState3& s, const GeluK3 k, const
 // in bf16) and the kernels stage 0.5 b1: the accumulator IS z = 0.5 v, the scaling step is gone.  Five vector instructions and one
 // transcendental per element instead of eight and one; same seven-step interface as gelu3_micro (steps 4-6 are empty), result in
 // (s.qx, s.qy).  ax / ay are read by steps 0-3.
-constexpr bool kBf16FusedHalfW1 = true;       // api.hip packs wstream_b / wstream_p with 0.5 W1; the fused bf16 kernels stage 0.5 b1
+constexpr bool kBf16FusedHalfW1 = true;       // api.hip packs wstream_b with 0.5 W1; the fused bf16 kernels stage 0.5 b1
 __device__ __forceinline__ GeluK3 gelu_k2h() {
     GeluK3 k;
     k.zs = 1.0f; k.k3 = 0.f; k.k4 = 0.f;

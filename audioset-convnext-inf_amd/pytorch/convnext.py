@@ -131,6 +131,7 @@ class ConvNeXt(nn.Module):
         # arithmetic of the dense contractions (include/acx.h, enum acx_precision).  "fp32_split" and "fp32" are both
         # fp32-grade (same parity tests, same tolerances); split is the fast one.  ACX_PRECISION overrides the default.
         self.precision = os.environ.get("ACX_PRECISION", "fp32_split")
+        self.frontend = os.environ.get("ACX_FRONTEND", "auto")       # set_frontend()
         if self.precision not in _ffi.PRECISIONS:
             raise ValueError("ACX_PRECISION must be one of %s" % sorted(_ffi.PRECISIONS))
         self._ws = {}           # (device index, stream handle) -> workspace tensor: concurrent forwards on different
@@ -161,7 +162,7 @@ class ConvNeXt(nn.Module):
                 dicts = [(m._parameters, m._buffers, m._modules) for m in self.modules()]
                 c = self._sig_cache = (self._weights_epoch, dicts,
                                        tuple(id(x) for _, _, ch in dicts for x in ch.values()))
-            sig = [self.precision, self._weights_epoch]
+            sig = [self.precision, self.frontend, self._weights_epoch]
             kids = []
             for params, bufs, children in c[1]:
                 for t in params.values():
@@ -240,6 +241,16 @@ class ConvNeXt(nn.Module):
         self.precision = precision
         return self
 
+    def set_frontend(self, mode):
+        """"auto" (default): the FFT kernel evaluates torchlibrosa's STFT whenever the stored `conv_real` / `conv_imag` buffers
+        are window x DFT.  "dense": always the reference's own formulation -- the two Conv1d as one dense contraction with the
+        stored weights (convnext.py:179-187,298) -- and thereby its rounding: the parity mode for pure tones and clean sweeps,
+        whose bins 90 dB under the frame peak the two formulations round differently (include/acx.h, acx_set_frontend)."""
+        if mode not in _ffi.FRONTENDS:
+            raise ValueError("frontend must be one of %s" % sorted(_ffi.FRONTENDS))
+        self.frontend = mode
+        return self
+
     def native_context(self, device):
         """The libacx context holding this module's weights on `device` (rebuilt when they change)."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -249,6 +260,7 @@ class ConvNeXt(nn.Module):
             return hit[0]
         ctx = hit[0] if hit is not None else _ffi.Context(idx)
         ctx.set_precision(self.precision)
+        ctx.set_frontend(self.frontend)
         ctx.load_state_dict(self.state_dict())
         self._ctx[idx] = (ctx, sig)
         return ctx

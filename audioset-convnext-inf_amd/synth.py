@@ -188,3 +188,57 @@ def synth_waveforms(batch, length, seed=1234, kind="noise", device="cpu"):
     else:
         raise ValueError("unknown kind %r" % kind)
     return x.contiguous().to(device)
+
+
+# ---- frontend probe family (round 6, tests/golden/make_frontend_goldens.py, tests/test_gpu_frontend_edge.py) -----------------
+# Signals whose STFT has bins far below the frame peak -- where the FFT kernel and the reference's dense DFT round differently
+# and bn0 amplifies the difference (the thin end of the 1e-3 parity margin): tones at and between bin centres, a 10 s chirp,
+# an impulse train, DC + faint noise, one full-scale click over digital silence, a loud burst over near-silence.
+FRONTEND_PROBES = (
+    # name, samples
+    ("tone_bin_centre", 32000),      # 3125 Hz = bin 100 exactly, amplitude 0.5
+    ("tone_between_bins", 32000),    # bin 100.5
+    ("tone_fmin", 32000),            # 50 Hz = the mel bank's lower edge (bin 1.6)
+    ("two_tones_60db", 32000),       # bin 64 at 0.5 + bin 300.25 at 0.0005
+    ("impulse_train", 32000),        # 0.9 every 1000 samples
+    ("dc_noise", 32000),             # DC 0.5 + N(0, 0.01^2)
+    ("chirp_10s", 320000),           # 20 Hz -> 15.9 kHz linear, amplitude 0.5
+    ("click_silence_10s", 320000),   # digital silence, one sample at +1.0
+    ("burst_quiet_10s", 320000),     # N(0, 1e-5^2) with 10 ms of full-scale noise at 5 s
+)
+
+
+def frontend_probe(name):
+    """(1, L) fp32 waveform of one probe; float64 arithmetic rounded once."""
+    L = dict(FRONTEND_PROBES)[name]
+    t = np.arange(L, dtype=np.float64)
+    bin_hz = ft.SAMPLE_RATE / 1024.0
+
+    def tone(b, amp):
+        return amp * np.sin(2 * np.pi * b * bin_hz * t / ft.SAMPLE_RATE)
+    if name == "tone_bin_centre":
+        x = tone(100.0, 0.5)
+    elif name == "tone_between_bins":
+        x = tone(100.5, 0.5)
+    elif name == "tone_fmin":
+        x = 0.5 * np.sin(2 * np.pi * 50.0 * t / ft.SAMPLE_RATE)
+    elif name == "two_tones_60db":
+        x = tone(64.0, 0.5) + tone(300.25, 0.0005)
+    elif name == "impulse_train":
+        x = np.where(t % 1000 == 0, 0.9, 0.0)
+    elif name == "dc_noise":
+        x = 0.5 + 0.01 * np.random.RandomState(601).randn(L)
+    elif name == "chirp_10s":
+        dur = L / ft.SAMPLE_RATE
+        ts = t / ft.SAMPLE_RATE
+        x = 0.5 * np.sin(2 * np.pi * (20.0 * ts + 0.5 * (15900.0 - 20.0) / dur * ts * ts))
+    elif name == "click_silence_10s":
+        x = np.zeros(L)
+        x[L // 2] = 1.0
+    elif name == "burst_quiet_10s":
+        rs = np.random.RandomState(602)
+        x = 1e-5 * rs.randn(L)
+        x[160000:160320] = np.clip(0.5 * rs.randn(320), -1.0, 1.0)
+    else:
+        raise ValueError("unknown probe %r" % name)
+    return torch.from_numpy(x.astype(np.float32))[None, :].contiguous()

@@ -76,47 +76,6 @@ def test_block_bf16(ctx16, model16, taps, synth_sd, s, rows):
     _block_check(ctx16, model16, taps, synth_sd, s, rows)
 
 
-@pytest.fixture
-def paired_kernel(monkeypatch):
-    """ACX_BF16_PAIR=1: the producer / consumer form of the fused bf16 MLP (mlp_pair_bf16.hip) instead of the ring kernels."""
-    refresh = _ffi.lib().acx_tuning_refresh
-    monkeypatch.setenv("ACX_BF16_PAIR", "1")
-    refresh()
-    yield
-    monkeypatch.delenv("ACX_BF16_PAIR", raising=False)
-    refresh()
-
-
-@pytest.mark.parametrize("rows", [None, 3])
-@pytest.mark.parametrize("s", [1, 2])
-def test_block_bf16_paired_kernel(paired_kernel, ctx16, model16, taps, synth_sd, s, rows):
-    """The same check against the same emulation on the paired kernel (stages 1-2: C = 192 with two pixel tiles per pair,
-    C = 384 with one; `rows = 3` fills no tile and runs the masked epilogue)."""
-    _block_check(ctx16, model16, taps, synth_sd, s, rows)
-
-
-def test_forward_paired_kernel_vs_ring_kernel(model16):
-    """Whole forward, 3 clips of 10 s (several tiles per workgroup, both LayerNorm-output epilogues): the paired kernels against
-    the ring kernels -- same operand roundings, different fp32 summation order (the residual enters the accumulator first)."""
-    from audioset_convnext_inf_amd import synth
-    wav = synth.synth_waveforms(3, 320000, seed=17).cuda()
-    ring = model16(wav)["clipwise_logits"].clone()
-    refresh = _ffi.lib().acx_tuning_refresh
-    os.environ["ACX_BF16_PAIR"] = "1"
-    refresh()
-    try:
-        pair = model16(wav)["clipwise_logits"].clone()
-        again = model16(wav)["clipwise_logits"].clone()
-    finally:
-        del os.environ["ACX_BF16_PAIR"]
-        refresh()
-    torch.cuda.synchronize()
-    assert bool(torch.isfinite(pair).all()) and torch.equal(pair, again)
-    d = maxdiff(pair, ring)
-    print("%s: paired vs ring kernels, logits max abs diff %.3g" % (model16.precision, d))
-    assert d < 2e-2          # (bf16 drift vs fp32 is 1.2e-2 on logits; two bf16 arithmetics that differ in summation order stay inside it)
-
-
 def _block_check(ctx16, model16, taps, synth_sd, s, rows):
     from oracle import ref_cpu
     C = DIMS[s]

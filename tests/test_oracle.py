@@ -104,3 +104,67 @@ def test_frontend_tables_agree():
         nz = np.nonzero(m[:, c])[0]
         assert len(nz) >= 1 and nz[-1] - nz[0] + 1 == len(nz)
         assert nz[0] * 31.25 >= 50 and nz[-1] * 31.25 <= 14000
+
+
+def test_oracle_g5_frontend_probes(synth_sd, golden_dir):
+    """The frontend probe family (tests/golden/make_frontend_goldens.py): oracle against the reference class's outputs.  Bit-equal in
+    the build container; another host's BLAS may sum the STFT in another order, which on these probes moves the outputs by up to the
+    recorded `reference_stft_rounding_sensitivity` (tests/golden/frontend_self_noise.py) -- the bar is twice that, at least 1e-5."""
+    import hashlib
+    g = np.load(os.path.join(golden_dir, "g5_frontend.npz"))
+    sens = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["reference_stft_rounding_sensitivity"]
+    for name, L in synth.FRONTEND_PROBES:
+        if L > 32000 and name != "chirp_10s":
+            continue                                            # one 10 s probe is enough on the CPU
+        wav = synth.frontend_probe(name)
+        assert hashlib.sha256(wav.numpy().tobytes()).digest() == bytes(g[name + "/sha256"])
+        o = ref_cpu.forward(synth_sd, wav)
+        fr = ref_cpu.forward_frame_embeddings(synth_sd, wav)
+        for key, got in (("logits", o["clipwise_logits"]), ("frame", fr)):
+            d = float((got.double() - torch.from_numpy(g[name + "/" + key]).double()).abs().max())
+            assert d <= max(1e-5, 2.0 * sens[name][key]), (name, key, d)
+
+
+def test_mel_bank_properties_independent_of_the_product_tables():
+    """What librosa 0.8.1's `filters.mel(sr=32000, n_fft=1024, n_mels=224, fmin=50, fmax=14000)` must look like, checked on the
+    matrix the PRODUCT ships (frontend_tables.mel_matrix) with arithmetic written here and nowhere else (the
+    library itself is absent and no checkpoint is at hand to pin the table bit for bit):
+      * Slaney scale: 226 points equally spaced in mel between mel(50 Hz) and mel(14 kHz), linear (200/3 Hz per mel) below the
+        1 kHz knee, logarithmic (27 mel per factor 6.4) above -- every filter's centroid sits at the mean of its three points;
+      * Slaney area normalisation: every triangle integrates to 1 over frequency;
+      * triangles: non-negative, one contiguous band each, rising then falling, neighbours overlapping half-way."""
+    m = ft.mel_matrix().astype(np.float64)                    # (513, 224)
+    assert m.shape == (513, 224) and (m >= 0).all()
+    bin_hz = 32000.0 / 1024.0
+    f = np.arange(513) * bin_hz
+
+    def mel(hz):
+        return hz / (200.0 / 3.0) if hz < 1000.0 else 15.0 + np.log(hz / 1000.0) / (np.log(6.4) / 27.0)
+
+    def hz(ml):
+        return ml * (200.0 / 3.0) if ml < 15.0 else 1000.0 * np.exp((ml - 15.0) * (np.log(6.4) / 27.0))
+
+    lo, hi = mel(50.0), mel(14000.0)
+    pts = np.array([hz(lo + (hi - lo) * i / 225.0) for i in range(226)])
+    assert abs(pts[0] - 50.0) < 1e-9 and abs(pts[-1] - 14000.0) < 1e-6
+    knee = int(np.searchsorted(pts, 1000.0))
+    assert 50 < knee < 70                                                        # 57 points lie below 1 kHz
+    assert np.allclose(np.diff(pts[:knee]), np.diff(pts[:knee])[0], rtol=1e-9)   # equal steps in Hz below the knee
+    assert np.allclose(pts[knee + 1:] / pts[knee:-1], pts[knee + 1] / pts[knee], rtol=1e-9)     # equal ratios above it
+    n_wide = 0
+    for c in range(224):
+        w = m[:, c]
+        nz = np.nonzero(w)[0]
+        a, ctr, b = pts[c], pts[c + 1], pts[c + 2]
+        # support: the bins strictly inside (a, b)
+        inside = np.nonzero((f > a) & (f < b))[0]
+        assert len(nz) >= 1 and nz[0] >= inside[0] and nz[-1] <= inside[-1] and len(nz) >= len(inside) - 0, (c, nz, inside)
+        # the exact triangle, sampled: height 2 / (b - a) at ctr
+        tri = np.maximum(0.0, np.minimum((f - a) / (ctr - a), (b - f) / (b - ctr))) * (2.0 / (b - a))
+        assert np.abs(w - tri).max() <= 2e-7 * tri.max() + 1e-12, (c, np.abs(w - tri).max())
+        # area 1 and centroid at the mean of the three points (a SAMPLED triangle: checked where it spans >= 10 bins)
+        if len(nz) >= 10:
+            n_wide += 1
+            assert abs(w.sum() * bin_hz - 1.0) < 0.05, (c, w.sum() * bin_hz)
+            assert abs((w * f).sum() / w.sum() - (a + ctr + b) / 3.0) < 0.5 * bin_hz
+    assert n_wide >= 20

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = os.environ.get("ACX_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 # kernels (namespace acx) that run dense 16-bit MFMA on live data
 EXCLUSIVE = ("gemm_split_kernel", "gemm_split16_kernel", "mlp_fused_split_kernel", "mlp_fused_wide_kernel", "mlp_fused_wide_bf16_kernel",
-             "mlp_fused_stat_bf16_kernel", "mlp_pair_bf16_kernel", "gemm_bf16_kernel")
+             "mlp_fused_stat_bf16_kernel", "gemm_bf16_kernel", "dwconv7_mfma_kernel")
 
 
 def kernels_of(lib):

@@ -26,6 +26,18 @@
 #include "acx_internal.h"
 #include "split_math.h"
 
+// Round 6: this kernel left libacx.so (measured no faster in the forward); it builds only inside
+// tools/lab/pair_lab.hip.  The lab hands its stream in through BlockW::wstream_b (the packing of this kernel -- 32-hidden-unit
+// segments at pos_w1 / pos_w2 -- is in the git history of api.hip, round 5).
+namespace acx {
+bool mlp_pair_bf16_supported(int C);
+int mlp_pair_bf16_swz(int C, int row);
+int mlp_pair_bf16_pos_w1(int C, int k);
+int mlp_pair_bf16_pos_w2(int C, int j);
+int launch_mlp_pair_bf16(acx_ctx* c, const BlockW& w, int C, const void* y, void* x, long long M, hipStream_t s,
+                         void* ln_out, int ld_out, bool act_bf16);
+}
+
 namespace acx {
 
 typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
@@ -598,7 +610,7 @@ static int launch_pair_cfg(const BlockW& w, const void* y, void* x, long long M,
     if (share < 1) share = 1;
     const long long blocks = tiles < share ? tiles : share;
     launch_kernel(&mlp_pair_bf16_kernel<C, PT, LNOUT, ABF>, dim3((unsigned)blocks), dim3(512), kCuLdsBytes /* CU-exclusive */, s,
-        y, x, reinterpret_cast<const char*>(w.wstream_p), w.b1, w.b2, M, ld_out, reinterpret_cast<__bf16*>(ln_out));
+        y, x, reinterpret_cast<const char*>(w.wstream_b), w.b1, w.b2, M, ld_out, reinterpret_cast<__bf16*>(ln_out));
     ACX_HIP(hipGetLastError());
     return ACX_OK;
 }
@@ -617,7 +629,7 @@ static int launch_pair_any(const BlockW& w, int C, const void* y, void* x, long 
 
 int launch_mlp_pair_bf16(acx_ctx* c, const BlockW& w, int C, const void* y, void* x, long long M, hipStream_t s,
                          void* ln_out, int ld_out, bool act_bf16) {
-    if (!w.wstream_p) ACX_FAIL(ACX_ERR_STATE, "paired bf16 MLP: the weight stream was not packed for C=%d", C);
+    if (!w.wstream_b) ACX_FAIL(ACX_ERR_STATE, "paired bf16 MLP: the weight stream was not packed for C=%d", C);
     ProfScope ps(c, ACX_K_MLP_WIDE, s);
     return act_bf16 ? launch_pair_any<true>(w, C, y, x, M, s, ln_out, ld_out) : launch_pair_any<false>(w, C, y, x, M, s, ln_out, ld_out);
 }

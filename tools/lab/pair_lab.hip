@@ -1,5 +1,5 @@
 // Stand-alone timing lab for the paired fused bf16 MLP (mlp_pair_bf16.hip; not part of libacx):
-//   hipcc -O3 -std=c++17 -fno-slp-vectorize --offload-arch=gfx950 -w -DPAIR_C=384 -DPAIR_SRC='"<path>/mlp_pair_bf16.hip"' tools/lab/pair_lab.hip -o /tmp/pair_lab
+//   hipcc -O3 -std=c++17 -fno-slp-vectorize --offload-arch=gfx950 -w -DPAIR_C=384 -Iaudioset-convnext-inf_amd/csrc -DPAIR_SRC='"mlp_pair_bf16.hip"' -Itools/lab tools/lab/pair_lab.hip -o /tmp/pair_lab
 //   /tmp/pair_lab [M]      default M = the stage's pixel count at B = 64
 // -DACX_PAIR_STAMPS: prints, for the first tile of the first 64 workgroups, the median cycles of every interval of producer wave 0 and
 // consumer wave 4: [work before the mark | gelu or nothing | MFMA phase | wait + barrier].
@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
         hipMemcpy(w, hw.data(), wbytes, hipMemcpyHostToDevice);
     }
     acx::BlockW bw;
-    bw.wstream_p = reinterpret_cast<uint16_t*>(w); bw.b1 = b1; bw.b2 = b2;
+    bw.wstream_b = reinterpret_cast<uint16_t*>(w); bw.b1 = b1; bw.b2 = b2;
 #define CALL() acx::launch_mlp_pair_bf16(nullptr, bw, C, y, x, M, 0, nullptr, 0, true)
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 5; ++i) if (CALL() != 0) return 1;
