@@ -51,7 +51,7 @@ SIGNATURES = {
     "acx_frontend_info": (_c_int, [_vp, _pint, ctypes.POINTER(ctypes.c_float), _pint]),
     "acx_set_frontend": (_c_int, [_vp, _c_int]),
     "acx_tuning_refresh": (_c_int, []),
-    "acx_test_fail_sub": (_c_int, [_c_int]),
+    "acx_test_fail_sub": (_c_int, [_vp, _c_int]),
     "acx_profile_enable": (_c_int, [_vp, _c_int]),
     "acx_profile_read": (_c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64)]),
 }

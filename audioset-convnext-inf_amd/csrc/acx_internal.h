@@ -203,6 +203,7 @@ struct acx_ctx {
     // identity affine for acx_logmel_bn0(apply_bn0 = 0) (tests): per context, i.e. per device
     float* d_bn_one = nullptr;
     float* d_bn_zero = nullptr;
+    std::atomic<int> fail_sub{-1}; // acx_test_fail_sub(ctx, i): THIS context's acx_forward reports a failure after queueing sub-batch i (error-path tests); cleared by acx_finalize
     void* comm = nullptr;          // RCCL communicator (comm.hip), owned; null until acx_comm_init
     int comm_rank = 0, comm_world = 1;
     void* d_dw_sink = nullptr;     // kDwSinkBytes: where the column-streaming depthwise kernel stores rows that are not image rows
@@ -226,7 +227,6 @@ struct Tuning {
     std::atomic<int> gemm_mi{0};       // ACX_GEMM_MI = 1 | 2 | 4: row blocks per wave of the split / bf16 GEMM tiles (0: by launch size)
     std::atomic<int> wide_npb{0};      // ACX_WIDE_NPB = 1 | 2: pixel blocks per wave of the wide fused MLP (0: by launch size)
     std::atomic<int> gemm_32x32{0};    // ACX_GEMM_32X32 = 1: the 32x32x16 form of the split GEMM
-    std::atomic<int> fail_sub{-1};     // acx_test_fail_sub(i): acx_forward reports a failure after queueing sub-batch i (error-path tests; never read from the environment)
     std::atomic<int> wide_pers{0};     // ACX_WIDE_PERSIST: 1 = persistent wide fused MLP wherever it exists, 2 = never; 0 = by launch size
     std::atomic<int> dwm_waves{0};     // ACX_DWM_WAVES = 2..9: the matrix-pipe depthwise launch asks for that many waves per CU of its share (0: 8 = two per SIMD)
     std::atomic<int> dw_mfma{-1};      // ACX_DW_MFMA = 0: bf16 activations go through the column / tile depthwise kernels instead of the matrix-pipe kernel (A/B timing: other bits)

@@ -761,6 +761,7 @@ int acx_set_weight(acx_ctx* c, const char* key, const float* host_data, const in
 
 int acx_finalize(acx_ctx* c) {
     if (!c) ACX_FAIL(ACX_ERR_ARG, "null context");
+    c->fail_sub.store(-1, std::memory_order_relaxed);       // an armed test hook never outlives the weights it was armed on
     int rc = finalize_impl(c);
     if (rc != ACX_OK) { free_device(c); }
     return rc;
@@ -852,7 +853,6 @@ static int get_aux(acx_ctx* c, hipStream_t st, acx_ctx::Aux* out, bool* found) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return ACX_OK;
         acx_ctx::AuxEntry e;
-        ACX_TRY(make_aux(&e.a));
         if (c->aux.size() >= kMaxAuxStreams) {          // drop the least recently used set nobody is queueing on
             auto victim = c->aux.end();
             for (auto d = c->aux.begin(); d != c->aux.end(); ++d)
@@ -861,10 +861,19 @@ static int get_aux(acx_ctx* c, hipStream_t st, acx_ctx::Aux* out, bool* found) {
             if (victim != c->aux.end()) {
                 // retired, not destroyed: destroying a stream that still has work means synchronising it, which stalls every
                 // forward waiting for aux_mutex and is an illegal call while ANY stream of the process captures in global
-                // mode.  A set is two streams and three events; acx_destroy releases the retired ones.
+                // mode.  The retired sets are a FREE POOL: fork and join are ordered by events alone,
+                // so a set whose old work is still draining can serve a new caller stream as it is -- a context called from
+                // ever-new streams (per-request streams, private capture streams) recycles kMaxAuxStreams + pool sets for ever
+                // instead of leaking two streams and three events per eviction.
                 c->aux_retired.push_back(victim->second.a);
                 c->aux.erase(victim);
             }
+        }
+        if (!c->aux_retired.empty()) {
+            e.a = c->aux_retired.back();
+            c->aux_retired.pop_back();
+        } else {
+            ACX_TRY(make_aux(&e.a));
         }
         it = c->aux.emplace(st, e).first;
     }
@@ -962,7 +971,7 @@ int acx_forward(acx_ctx* c, const float* wav, int B, int64_t L, int mode, float*
                              out1 ? out1 + b_off * per_clip : nullptr, ws + ws_off, pi, si);
             ws_off += pi.total;
             b_off += Bi;
-            if (rc == ACX_OK && tuning().fail_sub.load(std::memory_order_relaxed) == i) {
+            if (rc == ACX_OK && c->fail_sub.load(std::memory_order_relaxed) == i) {
                 set_error("test hook acx_test_fail_sub: failure injected after sub-batch %d", i);
                 rc = ACX_ERR_STATE;
             }
@@ -1080,9 +1089,10 @@ int acx_tuning_refresh(void) {
     return ACX_OK;
 }
 
-int acx_test_fail_sub(int sub) {
+int acx_test_fail_sub(acx_ctx* c, int sub) {
+    if (!c) ACX_FAIL(ACX_ERR_ARG, "null context");
     if (sub < -1 || sub >= acx_ctx::kMaxSplitWays) ACX_FAIL(ACX_ERR_ARG, "acx_test_fail_sub: sub-batch index %d", sub);
-    tuning().fail_sub.store(sub, std::memory_order_relaxed);
+    c->fail_sub.store(sub, std::memory_order_relaxed);
     return ACX_OK;
 }
 

@@ -698,7 +698,7 @@ int launch_dwconv(acx_ctx* c, const BlockW& w, int C, const void* x, void* y, fl
             const int per_cu = tuning().dwm_waves.load(std::memory_order_relaxed);
             return launch_dwconv_mfma(x, y, w.dw_ops, w.dwb, c->d_dw_sink, B, H, W, (per_cu ? per_cu : 8) * cus / inflight_ways(), s);
         }
-        if (C == 96 * 56 / (W > 0 ? W : 1) && !(W == 7 && act_bf16) && use_col_kernel(c, B, H, W, act_bf16, &target_waves)) {
+        if (C == 96 * 56 / (W > 0 ? W : 1) && !act_bf16 && use_col_kernel(c, B, H, W, act_bf16, &target_waves)) {
             rc = launch_dwconv_col(x, y, w.dw, w.dwb, c->d_dw_sink, B, H, W, act_bf16, target_waves, s);
             ACX_TRY(rc);
             if (stats) ACX_TRY(launch_rowstats(c, reinterpret_cast<const float*>(y), stats, (int64_t)B * H * W, C, s));

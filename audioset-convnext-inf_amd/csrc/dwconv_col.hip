@@ -435,15 +435,15 @@ static int launch_dw_col_cfg(const void* x, void* y, const float* wt, const floa
 // wave, every 4 from two) on half-length segments, whose extra halo rows come from the cache or weigh half.
 int launch_dwconv_col(const void* x, void* y, const float* wt, const float* bias, void* sink, int B, int H, int W,
                       bool act_bf16, int target_waves, hipStream_t s) {
+    // bf16 activations never come here in production: every launch of `bf16a` takes the matrix-pipe kernel (dwconv_mfma.hip), and
+    // the diagnostic switch ACX_DW_MFMA=0 falls back to the tile / ring kernels of dwconv.hip (same bits as this kernel).  Round 6
+    // removed the 21 bf16 instantiations of this file (1.2 MB of code objects no launch selected).
+    if (act_bf16) ACX_FAIL(ACX_ERR_STATE, "dwconv7 (column form): bf16 activations take the matrix-pipe kernel");
     switch (W) {
-        case 56: return act_bf16 ? launch_dw_col_cfg<56, true, 7, 2>(x, y, wt, bias, sink, B, H, target_waves, s)
-                                 : launch_dw_col_cfg<56, false, 7, 1>(x, y, wt, bias, sink, B, H, target_waves, s);
-        case 28: return act_bf16 ? launch_dw_col_cfg<28, true, 7, 2>(x, y, wt, bias, sink, B, H, target_waves, s)
-                                 : launch_dw_col_cfg<28, false, 7, 1>(x, y, wt, bias, sink, B, H, target_waves, s);
-        case 14: return act_bf16 ? launch_dw_col_cfg<14, true, 7, 2>(x, y, wt, bias, sink, B, H, target_waves, s)
-                                 : launch_dw_col_cfg<14, false, 4, 2>(x, y, wt, bias, sink, B, H, target_waves, s);
-        case 7: if (!act_bf16) return launch_dw_col_cfg<7, false, 5, 2>(x, y, wt, bias, sink, B, H, target_waves, s);
-                ACX_FAIL(ACX_ERR_STATE, "dwconv7: stage 3 keeps fp32 activations");
+        case 56: return launch_dw_col_cfg<56, false, 7, 1>(x, y, wt, bias, sink, B, H, target_waves, s);
+        case 28: return launch_dw_col_cfg<28, false, 7, 1>(x, y, wt, bias, sink, B, H, target_waves, s);
+        case 14: return launch_dw_col_cfg<14, false, 4, 2>(x, y, wt, bias, sink, B, H, target_waves, s);
+        case 7: return launch_dw_col_cfg<7, false, 5, 2>(x, y, wt, bias, sink, B, H, target_waves, s);
         default: ACX_FAIL(ACX_ERR_SHAPE, "dwconv7: unsupported width %d (expected 56/28/14/7)", W);
     }
 }

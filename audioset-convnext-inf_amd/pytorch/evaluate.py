@@ -2,6 +2,7 @@
 (Evaluator :12-60) and `pytorch/pytorch_utils.py::forward` (:63-137): forward every batch under no_grad,
 concatenate clipwise outputs and targets, then per-class average precision, ROC-AUC and
 d' = sqrt(2) * Phi^-1(AUC) with exactly the sklearn / scipy calls the reference makes."""
+import threading
 from math import sqrt
 
 import numpy as np
@@ -57,6 +58,18 @@ class _Stager(object):
         self.dev32 = [None, None, None]           # float32 batches the model reads, in turn
         self.turn32 = 0
         self.fetch_stream = None                  # D2H of the scores, beside the compute stream
+
+    def close(self):
+        """Releases the pinned ring, the device buffers and the reader pool (release_stager / drop_stagers; the sweep that used them
+        has been synchronised)."""
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+            self.pool = None
+        self.pinned = [None] * self.kRing
+        self.ready = [None] * self.kRing
+        self.dev16 = [None] * self.kRing
+        self.dev16_read = [None] * self.kRing
+        self.dev32 = [None, None, None]
 
     def staged(self, x):
         if self.device.type != "cuda":
@@ -119,12 +132,17 @@ class _Stager(object):
         n = host.numel()
         d16 = self.dev16[slot]
         if d16 is None or d16.numel() < n:
-            with torch.cuda.stream(self.copy_stream):
-                d16 = self.dev16[slot] = torch.empty(n, dtype=torch.int16, device=self.device)
+            # (allocated on the CALLER's stream like d32 below, used on the copy stream behind explicit events: a replaced buffer
+            # goes back to the caching allocator only after the sweep's final synchronise has drained both streams -- forward())
+            if d16 is not None:
+                d16.record_stream(self.copy_stream)
+            d16 = self.dev16[slot] = torch.empty(n, dtype=torch.int16, device=self.device)
         t = self.turn32
         self.turn32 = (t + 1) % len(self.dev32)
         d32 = self.dev32[t]
         if d32 is None or d32.numel() < n:
+            if d32 is not None:
+                d32.record_stream(compute)
             d32 = self.dev32[t] = torch.empty(n, dtype=torch.float32, device=self.device)
         with torch.cuda.stream(self.copy_stream):
             if self.dev16_read[slot] is not None:           # the widening kernel that last read this buffer
@@ -157,22 +175,46 @@ def pcm16_to_float32(dev_int16):
     return out
 
 
-_STAGERS = {}
+_STAGERS = {}                    # device key -> _Stager; guarded by _STAGERS_LOCK
+_STAGERS_LOCK = threading.Lock()
+kAheadDepth = 2                  # batches the reader thread runs ahead of the consumer (_ahead)
+
+
+def _stager_key(device):
+    return (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0))
 
 
 def stager_for(device):
-    """The process-wide stager of `device`: its pinned ring is allocated once (pinning 4 x 164 MB costs tens of milliseconds --
-    a sweep of a few batches would spend a third of its time there if every forward() made its own)."""
-    import threading
-    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0),
-           threading.get_ident())       # (a sweep per thread: two concurrent sweeps never share a ring)
-    st = _STAGERS.get(key)
-    if st is None:
-        st = _STAGERS[key] = _Stager(device)
-    return st
+    """The stager of `device` for ONE sweep at a time: its pinned ring is allocated once per process (pinning 4 x 164 MB costs tens
+    of milliseconds -- a sweep of a few batches would spend a third of its time there if every forward() made its own).  A stager
+    is checked OUT of the per-device cache for the duration of a sweep and handed back by release_stager(); a second sweep on the
+    same device at the same time (another thread) gets a fresh one, which replaces the cached one when it comes back -- so the
+    cache holds at most one stager per device whatever the number or identity of threads (the round-5 cache was keyed
+    by thread id and never released)."""
+    with _STAGERS_LOCK:
+        st = _STAGERS.pop(_stager_key(device), None)
+    return st if st is not None else _Stager(device)
 
 
-def _ahead(generator, prepare, depth=2):
+def release_stager(stage):
+    """Hands a stager back (end of a sweep).  The sweep has drained: nothing reads its buffers any more."""
+    with _STAGERS_LOCK:
+        old = _STAGERS.get(_stager_key(stage.device))
+        _STAGERS[_stager_key(stage.device)] = stage
+    if old is not None and old is not stage:
+        old.close()
+
+
+def drop_stagers():
+    """Frees every cached stager (pinned ring, device buffers, reader pool): for long-lived processes that are done sweeping."""
+    with _STAGERS_LOCK:
+        olds = list(_STAGERS.values())
+        _STAGERS.clear()
+    for st in olds:
+        st.close()
+
+
+def _ahead(generator, prepare, depth=kAheadDepth):
     """Runs `generator` (and `prepare` on each item) in a background thread, `depth` batches ahead: reading the clips
     (memory-mapped shards), any host-side conversion and the copy into pinned memory overlap the GPU's work on the previous
     batch.  Exceptions re-raise in the consumer."""
@@ -268,6 +310,9 @@ def forward(model, generator, return_input=False, return_target=False):
     # The H2D copy of batch i + 1 is issued as soon as forward i has been queued -- a whole forward before its data is needed -- so
     # that a copy that lands on a hardware queue behind the library's own sub-batch stream still arrives in time.
     pending = None
+    # a pinned slot comes up again kRing batches later: the reader may be `depth` ahead, one batch is being staged and one is being
+    # read by the copy engine
+    assert _Stager.kRing >= kAheadDepth + 2, "pinned ring shorter than the read-ahead depth + 2"
     it = _ahead(generator, prepare)
     cur = next(it, None)
     x_cur = device_input(*cur) if cur is not None else None
@@ -284,8 +329,13 @@ def forward(model, generator, return_input=False, return_target=False):
         if pending is not None:
             collect(pending)                # waits for the PREVIOUS batch only (its own event, a side stream)
         pending = (batch, batch_out, done)
-    if pending is not None:
-        collect(pending)
+    try:
+        if pending is not None:
+            collect(pending)
+    finally:
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)      # the sweep has drained: the stager's buffers are idle when the next sweep takes them
+        release_stager(stage)
     return {k: np.concatenate(v, axis=0) for k, v in output.items()}
 
 

@@ -3,6 +3,8 @@ reading, clip padding.  Counterparts of reference `utils/utilities.py` (read_aud
 int16_to_float32 :226-227, float32_to_int16 :220-223, pad_or_truncate) and of the loading / padding lines of
 `demo_convnext.py:52-67` (torchaudio.load convention: PCM16 / 32768)."""
 import csv
+import json
+import os
 import struct
 
 import numpy as np
@@ -20,6 +22,19 @@ def read_audioset_label_tags(class_labels_indices_csv):
     id_to_ix = {mid: i for i, mid in enumerate(ids)}
     ix_to_id = {i: mid for i, mid in enumerate(ids)}
     return lb_to_ix, ix_to_lb, id_to_ix, ix_to_id
+
+
+def default_label_map():
+    """The same four dicts from the label table that ships with the package (metadata/audioset_class_labels.json: AudioSet's 527
+    classes in index order, generated from the reference's metadata/class_labels_indices.csv by tools/make_label_map.py) -- for
+    callers that have no CSV at hand (demo_convnext.py without --labels)."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "metadata", "audioset_class_labels.json")
+    with open(path, "r") as f:
+        classes = json.load(f)["classes"]
+    ids = [c[0] for c in classes]
+    labels = [c[1] for c in classes]
+    return ({label: i for i, label in enumerate(labels)}, {i: label for i, label in enumerate(labels)},
+            {mid: i for i, mid in enumerate(ids)}, {i: mid for i, mid in enumerate(ids)})
 
 
 def float32_to_int16(x):

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from audioset_convnext_inf_amd.pytorch.convnext import ConvNeXt, convnext_tiny      # noqa: E402
-from audioset_convnext_inf_amd.utils.utilities import read_audioset_label_tags, read_wav_pcm16, prepare_clip  # noqa: E402
+from audioset_convnext_inf_amd.utils.utilities import default_label_map, read_audioset_label_tags, read_wav_pcm16, prepare_clip  # noqa: E402
 
 
 def main():
@@ -66,10 +66,11 @@ def main():
     sample_labels = np.where(probs[0].clone().detach().cpu() > args.threshold)[0]
     print("Predicted labels using activity threshold %.2f:\n" % args.threshold)
     print(sample_labels)
-    if os.path.isfile(args.labels):
-        _, ix_to_lb, _, _ = read_audioset_label_tags(args.labels)
-        for l in sample_labels:
-            print("%s: %.3f" % (ix_to_lb[l], probs[0, l]))
+    # the reference reads metadata/class_labels_indices.csv (demo_convnext.py:29, utilities.py:195-216); without that file the
+    # packaged copy of the same table names the classes
+    _, ix_to_lb, _, _ = read_audioset_label_tags(args.labels) if os.path.isfile(args.labels) else default_label_map()
+    for l in sample_labels:
+        print("%s: %.3f" % (ix_to_lb[l], probs[0, l]))
 
     with torch.no_grad():
         scene = model.forward_scene_embeddings(waveform)

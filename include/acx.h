@@ -224,10 +224,11 @@ ACX_API int acx_frontend_info(const acx_ctx* ctx, int* dense_dft, float* stft_de
  * environment once, at the first acx_create; this re-reads them (tests force every tile shape through it and require
  * bit-identical results).  Launches never touch the environment.  No reference counterpart. */
 ACX_API int acx_tuning_refresh(void);
-/* Test support: make acx_forward report ACX_ERR_STATE after it has queued sub-batch `sub` (0 .. 3) of a split batch, so that
- * the error path -- joining the forked streams, ending a capture cleanly -- can be exercised; -1 switches it off (the default).
- * A call, not an environment variable: nothing in a production environment can arm it.  No reference counterpart. */
-ACX_API int acx_test_fail_sub(int sub);
+/* Test support: make THIS CONTEXT's acx_forward report ACX_ERR_STATE after it has queued sub-batch `sub` (0 .. 3) of a split batch,
+ * so that the error path -- joining the forked streams, ending a capture cleanly -- can be exercised; -1 switches it off (the
+ * default; acx_finalize also resets it).  Per context (a process-global switch could poison every other user of the
+ * library in the process), a call and not an environment variable.  No reference counterpart. */
+ACX_API int acx_test_fail_sub(acx_ctx* ctx, int sub);
 
 /* ---- measurement: per-kernel-class device time, HIP events on the launch stream ------------ */
 ACX_API int acx_profile_enable(acx_ctx* ctx, int on);

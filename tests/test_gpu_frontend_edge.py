@@ -114,8 +114,11 @@ def test_frontend_probe(edge_model, g5, name):
     assert all(np.isfinite(v) for v in res.values())
     outs = {k: res[k] for k in ("logits", "probs", "scene", "frame")}
     case = "frontend_edge/%s/%s/%s" % (name, edge_model.frontend, edge_model.precision)
-    # where signal is, both formulations agree with the reference to fp32 rounding of a dB value
-    assert res["logmel_db_top60"] < 2e-3, res
+    # where signal is (bins within 60 dB of the clip's peak) both formulations agree with the reference to fp32 rounding of a dB
+    # value -- or to the reference's own sensitivity there (DC + noise: the noise bins sit 55 dB under the DC leakage)
+    with open(parity_floor.MANIFEST) as f:
+        sens_db = json.load(f)["reference_stft_rounding_sensitivity"][name]["logmel_db"]
+    assert res["logmel_db_top60"] < max(2e-3, SENS_FACTOR[edge_model.frontend] * sens_db), res
     parity_floor.check(case, outs, contract(name, edge_model.frontend))
 
 

@@ -456,7 +456,10 @@ def test_failure_in_a_sub_batch_joins_the_forked_streams(model):
     capture an un-joined fork invalidates the capture (hipErrorStreamCaptureUnjoined at capture end), and the caller may free
     the workspace the side stream still uses.  The failure is injected by the library's test call acx_test_fail_sub (not an
     environment variable: ADVICE r04); the capture must END cleanly, and the model must work afterwards."""
-    fail_sub = _ffi.lib().acx_test_fail_sub
+    handle = model.native_context(torch.device("cuda", 0)).handle
+
+    def fail_sub(sub):                    # per context (ADVICE r05): other contexts of the process are not affected
+        return _ffi.lib().acx_test_fail_sub(handle, sub)
     wav = synth.synth_waveforms(17, 16000, seed=13).cuda()
     good = model(wav)["clipwise_logits"].clone()
     torch.cuda.synchronize()

@@ -18,6 +18,16 @@ def test_label_tags(tmp_path):
     assert lb_to_ix["Music"] == 2 and id_to_ix["/m/09x0r"] == 0 and ix_to_id[1] == "/m/05zppz"
 
 
+def test_packaged_label_map():
+    """The label table that ships with the package (527 AudioSet classes, index order): same four dicts as the CSV reader; the
+    reference's published demo answer `[0 137 138 139 151 506]` (README.md:57) names Speech / Music / instruments."""
+    lb_to_ix, ix_to_lb, id_to_ix, ix_to_id = ut.default_label_map()
+    assert len(ix_to_lb) == 527 and len(ix_to_id) == 527 and len(id_to_ix) == 527
+    assert ix_to_lb[0] == "Speech" and ix_to_id[0] == "/m/09x0r" and lb_to_ix["Speech"] == 0 and id_to_ix["/m/09x0r"] == 0
+    assert ix_to_lb[137] == "Music"
+    assert all(isinstance(v, str) and v for v in ix_to_lb.values())
+
+
 def test_pcm_scaling_conventions():
     x = np.array([-32768, -1, 0, 1, 32767], dtype=np.int16)
     np.testing.assert_array_equal(ut.int16_to_float32(x), (x / 32767.0).astype(np.float32))      # HDF5 path
