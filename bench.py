@@ -41,6 +41,11 @@ Extra objects on that line:
                   `frac_executed` (= frac) and `frac_algorithmic_vs_fp16_peak` (algorithmic flops against the
                   raw 2 500 TFLOP/s) are both given.
   kernels      -- the same for every kernel class, with the HBM roofline for the byte-bound ones.
+  traffic      -- (inside roofline / roofline_dwconv) HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
+                  --pmc passes, tools/pmc_table.py): for the headline workload measured LIVE by this invocation -- two rocprofv3
+                  child passes of tools/prof_step.py before the first GPU call of this process (`traffic_source` = "live: ...");
+                  for the other arithmetics / workloads, and if the profiler is unavailable, the newest committed summary of the
+                  same workload under profiles/ (`traffic_source` = its file name).
   cpu_baseline -- the CPU oracle (oracle/ref_cpu.py, torch-CPU fp32, the reference's op sequence) timed
                   on this box's host cores on a bounded sample of the same workload (N = 1, rank 0 only).
 """
@@ -140,13 +145,57 @@ def algorithmic_work(B, L, precision="fp32"):
     return work
 
 
+_LIVE_TRAFFIC = {}        # (precision, workload) -> (classes, source): filled by live_traffic() before the GPU is touched
+
+
+def live_traffic(precision="fp32_split"):
+    """HBM bytes per launch per kernel class of the headline workload (one forward of 64 x 10 s), measured NOW: two rocprofv3 --pmc
+    passes (FETCH_SIZE | WRITE_SIZE + GRBM_GUI_ACTIVE for the clock; separate passes and the gfx950 x2 correction of FETCH_SIZE as
+    MI355X_MICROARCH.md prescribes, tools/pmc_table.py) of tools/prof_step.py as child processes, run to completion before this
+    process makes its first GPU call (`traffic` used to be copied from profiles/ and could not contradict the
+    builder's pass).  Returns (classes, source) or None when rocprofv3 is missing or a pass fails -- the committed summary of the
+    same workload is then used and named as such."""
+    import glob
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="acx_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for tag, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE", "GRBM_GUI_ACTIVE"])):
+            cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "--", sys.executable,
+                                               os.path.join(ROOT, "tools", "prof_step.py"), "--precision", precision]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0 or not glob.glob(os.path.join(tmp, tag, "*", "*counter_collection.csv")):
+                print("bench.py: live PMC pass %s failed (rc %d): %s" % (tag, r.returncode, (r.stderr or "")[-300:]), file=sys.stderr)
+                return None
+        spec = importlib.util.spec_from_file_location("acx_pmc_table", os.path.join(ROOT, "tools", "pmc_table.py"))
+        pt = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(pt)
+        classes = pt.traffic_summary(pt.load(os.path.join(tmp, "fetch")), pt.load(os.path.join(tmp, "write")))
+        if not classes:
+            return None
+        return classes, "live: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE passes of tools/prof_step.py run by this bench.py invocation"
+    except Exception as e:       # noqa: BLE001 -- the headline must not depend on the profiler
+        print("bench.py: live PMC passes failed: %r" % (e,), file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def measured_traffic(precision="fp32_split", workload="bs64"):
-    """HBM bytes per launch per kernel class from the newest committed rocprofv3 PMC summary of THIS arithmetic and workload
-    ("bs64": one forward of 64 x 10 s; "frame256": forward_frame_embeddings at bs = 256) under profiles/ (tools/pmc_table.py:
-    FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes).  PMC counters cannot be read from inside this process, so `traffic`
-    is the profiled figure of the same workload, not a live measurement; the same files carry the shader clock
+    """HBM bytes per launch per kernel class (tools/pmc_table.py: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes): the LIVE passes of
+    this invocation when live_traffic() ran for this arithmetic and workload (the default run: fp32_split, 64 x 10 s), otherwise the
+    newest committed summary of THIS arithmetic and workload ("bs64": one forward of 64 x 10 s; "frame256": forward_frame_embeddings
+    at bs = 256) under profiles/.  `traffic_source` on the line says which.  The same source carries the shader clock
     (GRBM_GUI_ACTIVE / duration) the kernels of a class ran at in that pass."""
     import glob
+    if (precision, workload) in _LIVE_TRAFFIC:
+        return _LIVE_TRAFFIC[(precision, workload)]
     tag = {"fp32_split": "split", "bf16a": "bf16a", "bf16": "bf16", "fp32": "fp32"}[precision]
     if workload != "bs64":
         tag += "_" + workload
@@ -507,6 +556,9 @@ def main():
     if (world == 1 and not args.dry_run and not args.no_profile and not args.no_extra_configs and args.mode == "logits"
             and args.batch == 64 and args.precision == "fp32_split"):
         sweep_line = run_eval_sweep_child()          # before this process touches the GPU
+        live = live_traffic("fp32_split")            # likewise: counter passes as child processes
+        if live is not None:
+            _LIVE_TRAFFIC[("fp32_split", "bs64")] = live
     dist = None
     dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local_rank)
     if world > 1:
