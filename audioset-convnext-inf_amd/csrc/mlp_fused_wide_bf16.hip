@@ -112,6 +112,14 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
 #define ACX_WDMA(seg_, piece_, grp_)                                                                             \
         acx_glds16_s(wstream + (long long)(seg_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_)) * 1024, dma_voff,   \
                      smem_a + (unsigned)((grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + (piece_)) * 1024));
+    // In the segment loops the wave's kPieces pieces go out as RUNS (split_math.h acx_glds16_run_s): they are 1 KB apart in the stream
+    // and in the LDS, so one M0 write and one scalar base serve up to eight of them and a piece is ONE instruction instead of six
+    // (round 6: 144 -> 32 instructions per chunk at C = 384 in a loop that is bound by its instruction count).
+    // Nothing else touches M0 between the pieces of a run.
+#define ACX_WDMA_RUN(seg_, p_, grp_) {                                                                           \
+        const int run0_ = ((p_) / 8) * 8;                                                                       \
+        if ((p_) == run0_) acx_set_m0(smem_a + (unsigned)((grp_) * Cfg::kSegBytes + (wave * Cfg::kPieces + run0_ + 4) * 1024)); \
+        acx_glds16_run_s(wstream + (long long)(seg_) * Cfg::kSegBytes + (wave * Cfg::kPieces + run0_ + 4) * 1024, dma_voff, (p_) - run0_); }
 #pragma unroll
     for (int p = 0; p < Cfg::kPieces; ++p) ACX_WDMA(0, p, 0)
 #pragma unroll
@@ -186,24 +194,24 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
     // phase-1 unit u = (k-step s = u >> 1, X tile j = u & 1)
 #define ACX_W1_RD(base_, u_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) & 1) * (32 * 2 * C) + (((u_) >> 1) / kVar1) * (kVar1 * 32) + w1off[((u_) >> 1) % kVar1]))
     // MFMA number m_ of a segment is followed (behind a scheduling fence) by its share of the kHalf GELU micro-steps
-#define ACX_AFTER_MFMA(HV_, half_, m_)                                                                          \
-        ACX_FENCE if constexpr (HV_) { ACX_MICRO_RANGE(half_, Cfg::kHalf * (m_) / Cfg::kMfmas, Cfg::kHalf * ((m_) + 1) / Cfg::kMfmas) } ACX_FENCE
+#define ACX_AFTER_MFMA(HV_, half_, m_, X_)                                                                      \
+        ACX_FENCE if constexpr (HV_) { ACX_MICRO_RANGE(half_, Cfg::kHalf * (m_) / Cfg::kMfmas, Cfg::kHalf * ((m_) + 1) / Cfg::kMfmas, X_) } ACX_FENCE
 #define ACX_P1_MFMA(u_, f_)                                                                                     \
         _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
-            Xn[pt_][(u_) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ACX_B8(f_), ACX_B8(act[pt_][(u_) >> 1]), Xn[pt_][(u_) & 1], 0, 0, 0); \
-            ACX_AFTER_MFMA(HV, 1, (u_) * PT + pt_) }
+            Xb[CUR][pt_][(u_) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ACX_B8(f_), ACX_B8(act[pt_][(u_) >> 1]), Xb[CUR][pt_][(u_) & 1], 0, 0, 0); \
+            ACX_AFTER_MFMA(HV, 1, (u_) * PT + pt_, Xb[1 - CUR]) }
     // phase-2 unit u = (out tile t = u >> 2, k-step s' = u & 3)
 #define ACX_W2_RD(base_, u_) (*reinterpret_cast<const f32x4*>((base_) + ((u_) >> 2) * 4096 + w2off[(u_) & 3]))
 #define ACX_P2_MFMA(u_, f_)                                                                                     \
         _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                                  \
             acc[pt_][(u_) >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ACX_B8(f_), ACX_B8(g[pt_][(u_) & 3]), acc[pt_][(u_) >> 2], 0, 0, 0); \
-            ACX_AFTER_MFMA(HV, 0, (u_) * PT + pt_) }
+            ACX_AFTER_MFMA(HV, 0, (u_) * PT + pt_, Xb[CUR]) }
     // micro-steps [from, to) of the kHalf that segment half half_ carries: step sg_ belongs to pixel tile sg_ / 64; half h
     // is X tile j = h of the chunk: 8 register pairs x 8 steps (7 of the GELU, 1 bf16 pack) turn Xv[.][j] into un[.][j]
-#define ACX_MICRO_RANGE(half_, from_, to_)                                                                      \
+#define ACX_MICRO_RANGE(half_, from_, to_, X_)                                                                  \
         _Pragma("unroll") for (int sg_ = (from_); sg_ < (to_); ++sg_) {                                         \
             const int mt_ = sg_ / 64, pr_ = (sg_ % 64) / 8, st_ = sg_ % 8;                                      \
-            const float ax_ = Xv[mt_][half_][2 * pr_], ay_ = Xv[mt_][half_][2 * pr_ + 1];                       \
+            const float ax_ = X_[mt_][half_][2 * pr_], ay_ = X_[mt_][half_][2 * pr_ + 1];                       \
             if (st_ == 0) gelu2h_micro<0>(gs, gk, ax_, ay_);                                                     \
             else if (st_ == 1) gelu2h_micro<1>(gs, gk, ax_, ay_);                                                \
             else if (st_ == 2) gelu2h_micro<2>(gs, gk, ax_, ay_);                                                \
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
             const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + 64 * (k_) + 32 * j_ + 8 * q + 4 * hh);       \
             _Pragma("unroll") for (int pt_ = 0; pt_ < PT; ++pt_) {                                              \
-                Xn[pt_][j_][4 * q + 0] = bq[0]; Xn[pt_][j_][4 * q + 1] = bq[1]; Xn[pt_][j_][4 * q + 2] = bq[2]; Xn[pt_][j_][4 * q + 3] = bq[3]; } \
+                Xb[CUR][pt_][j_][4 * q + 0] = bq[0]; Xb[CUR][pt_][j_][4 * q + 1] = bq[1]; Xb[CUR][pt_][j_][4 * q + 2] = bq[2]; Xb[CUR][pt_][j_][4 * q + 3] = bq[3]; } \
         }
     // G of the chunk: k-step s' = 2 j + (pair >> 2) of phase 2 takes pairs 4 (s' & 1) .. + 3 of X tile j
 #define ACX_PACK_G()                                                                                            \
@@ -235,14 +243,19 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
         __builtin_amdgcn_s_barrier();                                                                           \
         ACX_FENCE
 
-    f32x16 Xn[PT][2], Xv[PT][2];  // Xn: pre-activation tiles being accumulated by phase 1; Xv: the previous chunk's, input of the GELU
+    // Two sets of pre-activation tiles in turn (round 6): phase 1 of chunk k accumulates into Xb[k & 1] while the second half of the
+    // GELU of chunk k - 1 reads Xb[(k - 1) & 1]; phase 2 then reads the first half of Xb[k & 1].  (Until round 5 one set was the
+    // accumulator and was copied to the other at the end of every phase 1: 32 v_accvgpr_read + 32 v_accvgpr_write per chunk and
+    // pixel tile, 8 % of the loop's instructions, in a loop bound by their count -- DESIGN.md 3i.)
+    f32x16 Xb[2][PT][2];
     f32x4 g[PT][4];               // G(k - 1): B operand of phase 2, four k-steps of 8 bf16
     unsigned un[PT][2][8];        // G(k) under construction
     constexpr int kDmaStride = Cfg::kUnits / Cfg::kPieces;
     GeluState3 gs;
 
-    auto phase1 = [&](auto with_gelu, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
-        constexpr bool HV = decltype(with_gelu)::value;     // second half (X tile 1) of the GELU of Xv rides on this segment's MFMAs
+    auto phase1 = [&](auto with_gelu, auto parity, const int k_, const int seg_, const int grp_) __attribute__((always_inline)) {
+        constexpr bool HV = decltype(with_gelu)::value;     // second half (X tile 1) of the GELU of the chunk before rides on this segment's MFMAs
+        constexpr int CUR = decltype(parity)::value;        // k_ & 1
         const char* base = smem + grp_ * Cfg::kSegBytes;
         const bool dma = seg_ + 2 < Cfg::kSegs;
         const int g2 = (grp_ + 2) % 3;
@@ -257,17 +270,16 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
             if (u + 2 < Cfg::kUnits) f[(u + 2) % 3] = ACX_W1_RD(base, u + 2);
             ACX_FENCE
             ACX_P1_MFMA(u, f[u % 3])
-            if (u % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, u / kDmaStride, g2) }
+            if (u % kDmaStride == 0 && dma) { ACX_WDMA_RUN(seg_ + 2, u / kDmaStride, g2) }
             ACX_FENCE
             if (u + 1 < Cfg::kUnits) ACX_TOUCH1(f[(u + 1) % 3])
         }
         if constexpr (HV) { ACX_PACK_G() }
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) { Xv[pt][0] = Xn[pt][0]; Xv[pt][1] = Xn[pt][1]; }
         ACX_SEG_END(dma)
     };
-    auto phase2 = [&](auto with_gelu, const int seg_, const int grp_) __attribute__((always_inline)) {
-        constexpr bool HV = decltype(with_gelu)::value;     // first half (X tile 0) of the GELU of Xv (the NEXT chunk) rides here
+    auto phase2 = [&](auto with_gelu, auto parity, const int seg_, const int grp_) __attribute__((always_inline)) {
+        constexpr bool HV = decltype(with_gelu)::value;     // first half (X tile 0) of the GELU of Xb[CUR] (the NEXT chunk) rides here
+        constexpr int CUR = decltype(parity)::value;
         const char* base = smem + grp_ * Cfg::kSegBytes;
         const bool dma = seg_ + 2 < Cfg::kSegs;
         const int g2 = (grp_ + 2) % 3;
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
             if (u + 2 < Cfg::kUnits) f[(u + 2) % 3] = ACX_W2_RD(base, u + 2);
             ACX_FENCE
             ACX_P2_MFMA(u, f[u % 3])
-            if (u % kDmaStride == 0 && dma) { ACX_WDMA(seg_ + 2, u / kDmaStride, g2) }
+            if (u % kDmaStride == 0 && dma) { ACX_WDMA_RUN(seg_ + 2, u / kDmaStride, g2) }
             ACX_FENCE
             if (u + 1 < Cfg::kUnits) ACX_TOUCH1(f[(u + 1) % 3])
         }
@@ -288,16 +300,23 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // segments 0 and 1 landed (the pieces are issued from asm: hipcc does not wait for them)
     __syncthreads();      // ... in every wave; b1s visible
-    phase1(std::false_type{}, 0, 0, 0);
-    ACX_MICRO_RANGE(0, 0, Cfg::kHalf)
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    static_assert(n % 2 == 0, "the chunk loop runs two chunks per iteration (the two X sets in turn)");
+    phase1(std::false_type{}, P0{}, 0, 0, 0);
+    ACX_MICRO_RANGE(0, 0, Cfg::kHalf, Xb[0])
     int grp = 1;
-    for (int k = 1; k < n - 1; ++k) {
-        phase1(std::true_type{}, k, 2 * k - 1, grp);
+    for (int k = 1; k < n - 1; k += 2) {
+        phase1(std::true_type{}, P1{}, k, 2 * k - 1, grp);
         grp = grp == 2 ? 0 : grp + 1;
-        phase2(std::true_type{}, 2 * k, grp);
+        phase2(std::true_type{}, P1{}, 2 * k, grp);
+        grp = grp == 2 ? 0 : grp + 1;
+        phase1(std::true_type{}, P0{}, k + 1, 2 * k + 1, grp);
+        grp = grp == 2 ? 0 : grp + 1;
+        phase2(std::true_type{}, P0{}, 2 * k + 2, grp);
         grp = grp == 2 ? 0 : grp + 1;
     }
-    phase1(std::true_type{}, n - 1, 2 * n - 3, grp);
+    phase1(std::true_type{}, P1{}, n - 1, 2 * n - 3, grp);
     grp = grp == 2 ? 0 : grp + 1;
     // the activations are dead from here on: their registers take the residual x of the tile
     // (not for LNOUT at C = 384: its epilogue needs every accumulator AND every residual value at once for the LayerNorm
@@ -342,14 +361,15 @@ __global__ __launch_bounds__(256) void mlp_fused_wide_bf16_kernel(
         _Pragma("unroll") for (int q = 0; q < 4; ++q) xr[pt][4 * t + q] = acx_ld4<ABF>(x, mrow[pt] * C + 4 * hh + 32 * t + 8 * q); \
     }
     if constexpr (!kLateX) { ACX_LOAD_XR() }
-    phase2(std::true_type{}, 2 * n - 2, grp);
+    phase2(std::true_type{}, P1{}, 2 * n - 2, grp);
     grp = grp == 2 ? 0 : grp + 1;
-    ACX_MICRO_RANGE(1, 0, Cfg::kHalf)       // second half of the last chunk's GELU: no phase-1 segment left to ride on
+    ACX_MICRO_RANGE(1, 0, Cfg::kHalf, Xb[1])       // second half of the last chunk's GELU: no phase-1 segment left to ride on
     ACX_PACK_G()
     if constexpr (kLateX) { ACX_LOAD_XR() }
-    phase2(std::false_type{}, 2 * n - 1, grp);
+    phase2(std::false_type{}, P1{}, 2 * n - 1, grp);
 #undef ACX_LOAD_XR
 #undef ACX_WDMA
+#undef ACX_WDMA_RUN
 #undef ACX_B8
 #undef ACX_FENCE
 #undef ACX_W1_RD
