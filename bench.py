@@ -552,6 +552,14 @@ def main():
         sys.exit(2)
     if args.dry_run and os.environ.get("ACX_BENCH_DRYRUN_FAIL_RANK") == str(rank):
         sys.exit(7)          # test hook (tests/test_host_cpu.py): a rank that dies before the rendezvous
+    # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The library drives two compute streams
+    # (the sub-batches) and the evaluation sweep two more (copy in, scores out): on TWO hardware queues the sweep reaches 0.93-0.98 of
+    # the resident rate where four give 0.87-0.89, and the resident forward itself is 0.7 % faster (same-box alternating runs,
+    # profiles/r06_e_hw_queues.txt).  The entry scripts of the package set the same default; an exported value wins.  Must be in
+    # the environment before the first HIP call of the process (and of the children below).  Multi-rank runs keep the runtime's
+    # default (RCCL brings streams of its own).
+    if world == 1 and not args.dry_run:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     sweep_line = None
     if (world == 1 and not args.dry_run and not args.no_profile and not args.no_extra_configs and args.mode == "logits"
             and args.batch == 64 and args.precision == "fp32_split"):
@@ -647,7 +655,7 @@ def main():
                                                         "tests as the native f32-MFMA path)" if split else
                                                         "fp32, native f32 MFMA (BASELINE configs[1])")),
                    "global_batch": world * B, "clip_samples": CLIP_SAMPLES, "weights": "seeded synthetic (synth.py)",
-                   "sub_batches": sub_batches,
+                   "sub_batches": sub_batches, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                    "parallelism": "clips sharded %d-way, full weight replica per GPU, RCCL all-gather of logits"
                                   % world if world > 1 else "single GPU"},
     }

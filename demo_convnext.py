@@ -11,8 +11,12 @@ import argparse
 import os
 import sys
 
-import numpy as np
-import torch
+# two hardware queues for this process's HIP streams (an exported value wins): the package's two sub-batch streams and the sweep's
+# copy streams overlap best on two -- bench.py and INTEGRATION.md have the measurement.  Before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
