@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box: per-kernel average durations (rocprofv3 --kernel-trace --stats) of the bf16a bench, one stream, for each value of
 # an environment switch.   bash tools/lab/ns_prof.sh VAR v1 v2 ...
-VAR=${1:-ACX_BF16_NSPLIT}; shift; VALS=${@:-0 1}
+VAR=${1:?environment switch, e.g. ACX_DW_MFMA}; shift; VALS=${@:-0 1}
 R=$PWD; export TMPDIR=/tmp
 for v in $VALS; do
   O=$R/gpurun_out/ns_prof_$v; rm -rf $O; mkdir -p $O
