@@ -209,6 +209,31 @@ def test_concurrent_forwards_on_two_streams(synth_sd):
         assert torch.equal(o1, r1) and torch.equal(o2, r2)
 
 
+def test_many_caller_streams_recycle_fork_join_sets(synth_sd):
+    """A context called from ever-new caller streams (per-request streams, private capture streams): the library keeps at most 16
+    fork / join sets, evicts the least recently used one nobody is queueing on and hands the evicted set to the next new stream
+    (api.hip get_aux: the retired sets are a free pool) -- 40 streams in turn, then the first ones again, two of them
+    at once: every result equals the serial one."""
+    m = make_model(synth_sd, "fp32_split")
+    w = synth.synth_waveforms(17, 32000, seed=43).cuda()          # 17 clips: two sub-batches, i.e. the fork / join path
+    ref = m(w)["clipwise_logits"].clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(40)]
+    outs = []
+    for s in streams:
+        with torch.cuda.stream(s):
+            outs.append(m(w)["clipwise_logits"])
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs)
+    for a, b in ((0, 39), (1, 20), (5, 6)):                        # evicted long ago, evicted recently, both evicted
+        with torch.cuda.stream(streams[a]):
+            oa = m(w)["clipwise_logits"]
+        with torch.cuda.stream(streams[b]):
+            ob = m(w)["clipwise_logits"]
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ref) and torch.equal(ob, ref)
+
+
 @pytest.mark.parametrize("precision", ["fp32_split", "bf16a"])
 def test_sub_batch_split_is_invisible(synth_sd, precision, monkeypatch):
     """acx_forward runs a batch as sub-batches on side streams (acx_sub_batches; default 2 from 16 clips up): whatever the
